@@ -1,0 +1,423 @@
+// bt_api.cpp -- the C ABI of libbendy_hip.so (include/bendy_hip.h): scene handles, parameter
+// preparation for Tracer::render (reference tracer/mod.rs:179-320) and kernel launches.
+// There is no CPU fallback: without a HIP device every render entry point returns BT_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "../../include/bendy_hip.h"
+#include "bt_scene.hpp"
+#include "bt_types.h"
+
+#pragma STDC FP_CONTRACT OFF
+
+extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t bt_launch_unshard(const float *gathered, float *frame, uint32_t width, uint32_t height,
+                                        uint32_t tiles_x, uint32_t tiles_y, uint32_t world, uint32_t tiles_per_rank,
+                                        hipStream_t stream);
+extern "C" hipError_t bt_launch_preview(const float *rgba, uint8_t *out, uint32_t n, uint32_t samples, int color_space,
+                                        hipStream_t stream);
+
+static_assert(BT_TILE == BT_TILE_DIM, "public and device tile sizes must agree");
+
+namespace {
+
+thread_local std::string g_error;
+int set_error(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+template <class T> struct DeviceArray {
+    T *ptr = nullptr;
+    size_t count = 0;
+    ~DeviceArray() { release(); }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    hipError_t upload(const std::vector<T> &src) {
+        release();
+        count = src.size();
+        size_t bytes = sizeof(T) * (count ? count : 1);
+        hipError_t e = hipMalloc((void **)&ptr, bytes);
+        if (e != hipSuccess) return e;
+        if (count) e = hipMemcpy(ptr, src.data(), sizeof(T) * count, hipMemcpyHostToDevice);
+        return e;
+    }
+};
+
+} // namespace
+
+struct bt_scene {
+    bt::Scene scene;
+    bt::FlatScene flat;
+    bool flat_valid = false;
+    bool device_valid = false;
+    int device = -1;
+    DeviceArray<BtPrim> d_prims;
+    DeviceArray<BtMaterial> d_materials;
+    DeviceArray<BtVolume> d_volumes;
+    DeviceArray<BtLight> d_lights;
+    DeviceArray<BtLightFace> d_light_faces;
+    DeviceArray<float> d_density;
+    unsigned long long *d_counters = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bt_stats last{};
+    bool stats_pending = false;
+
+    ~bt_scene() {
+        if (d_counters) (void)hipFree(d_counters);
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_stop) (void)hipEventDestroy(ev_stop);
+    }
+};
+
+namespace {
+
+#define BT_HIP(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return set_error(BT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)
+
+int ensure_flat(bt_scene *s) {
+    if (s->flat_valid) return 0;
+    try {
+        s->flat = bt::flatten_scene(s->scene);
+    } catch (const bt::Error &e) {
+        return set_error(e.code, e.message);
+    }
+    s->flat_valid = true;
+    s->device_valid = false;
+    return 0;
+}
+
+int ensure_device(bt_scene *s) {
+    int rc = ensure_flat(s);
+    if (rc) return rc;
+    int dev = -1;
+    BT_HIP(hipGetDevice(&dev));
+    if (s->device_valid && s->device == dev) return 0;
+    BT_HIP(s->d_prims.upload(s->flat.prims));
+    BT_HIP(s->d_materials.upload(s->flat.materials));
+    BT_HIP(s->d_volumes.upload(s->flat.volumes));
+    BT_HIP(s->d_lights.upload(s->flat.lights));
+    BT_HIP(s->d_light_faces.upload(s->flat.light_faces));
+    BT_HIP(s->d_density.upload(s->flat.density));
+    if (!s->d_counters) BT_HIP(hipMalloc((void **)&s->d_counters, 2 * sizeof(unsigned long long)));
+    if (!s->ev_start) BT_HIP(hipEventCreate(&s->ev_start));
+    if (!s->ev_stop) BT_HIP(hipEventCreate(&s->ev_stop));
+    s->device = dev;
+    s->device_valid = true;
+    return 0;
+}
+
+// ChunkConfig::with_configs (mod.rs:217-229) + camera setup (mod.rs:244-267)
+int fill_launch(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt_render_config *rc, uint32_t width,
+                uint32_t height, uint64_t seed, BtLaunch &P, int &output) {
+    if (!s || !cfg || !rc) return set_error(BT_ERR_INVALID_ARG, "null argument");
+    if (width == 0 || height == 0) return set_error(BT_ERR_INVALID_ARG, "zero-sized buffer");
+    int ci = s->scene.object_index(camera_ref);
+    if (ci < 0) return set_error(BT_ERR_INVALID_REF, "invalid object ref " + std::to_string(camera_ref));
+    const bt::Object &cam = s->scene.objects[ci];
+    if (cam.kind != bt::OBJ_CAMERA) return set_error(BT_ERR_NOT_CAMERA, "expected a camera object");
+
+    std::memset(&P, 0, sizeof P);
+    const bt::FlatScene &f = s->flat;
+    P.prims = s->d_prims.ptr;
+    P.materials = s->d_materials.ptr;
+    P.volumes = s->d_volumes.ptr;
+    P.lights = s->d_lights.ptr;
+    P.light_faces = s->d_light_faces.ptr;
+    P.density = s->d_density.ptr;
+    P.n_prims = (int32_t)f.prims.size();
+    P.n_materials = (int32_t)f.materials.size();
+    P.n_volumes = (int32_t)f.volumes.size();
+    P.n_lights = (int32_t)f.lights.size();
+    P.n_light_faces = (int32_t)f.light_faces.size();
+    P.n_density = (int32_t)f.density.size();
+    P.root_color = f.root_color;
+    P.root_albedo = f.root_albedo;
+    P.root_has_albedo = f.root_has_albedo;
+
+    P.cam_cx = cam.world.cx; P.cam_cy = cam.world.cy; P.cam_cz = cam.world.cz; P.cam_t = cam.world.t;
+    P.yfov = 2.0f * atan2f(cam.sensor_size, 2.0f * cam.focal_length);  // mod.rs:248
+    P.xfov = P.yfov * cam.aspect_ratio;                                // mod.rs:249
+    P.pixel_width = 2.0f * (1.0f / (float)width);                      // buffer.rs:68-71
+    P.pixel_height = 2.0f * (1.0f / (float)height);                    // buffer.rs:73-76
+    const uint32_t n = rc->subsample_n >= 2 ? rc->subsample_n : 1;     // mod.rs:47-67, main.rs:234-237
+    const float subpixel_scale = rc->subsample_n >= 2 ? 1.0f / (float)rc->subsample_n : 1.0f;
+    const float umin = -0.5f * P.pixel_width * subpixel_scale, umax = 0.5f * P.pixel_width * subpixel_scale;
+    const float vmin = -0.5f * P.pixel_height * subpixel_scale, vmax = 0.5f * P.pixel_height * subpixel_scale;
+    P.jitter_u_lo = umin;
+    P.jitter_u_scale = bt::uniform_scale(umin, umax, false);           // mod.rs:255-259
+    P.jitter_v_lo = vmin;
+    P.jitter_v_scale = bt::uniform_scale(vmin, vmax, false);           // mod.rs:261-265
+    P.has_focus = cam.has_focus ? 1 : 0;
+    P.focus = cam.focus;
+    P.aperture = 0.5f * cam.focal_length / cam.fstop;                  // mod.rs:289
+    BtV3 neg_z; neg_z.x = 0.0f; neg_z.y = 0.0f; neg_z.z = -1.0f;      // UnitDisk::new(Vec3::NEG_Z), mod.rs:267
+    bt::orthonormal_pair(neg_z, P.disk_x, P.disk_y);
+    P.tau_scale = bt::uniform_scale(0.0f, 6.28318530717958647692f, true);
+    P.one_scale = bt::uniform_scale(0.0f, 1.0f, true);
+
+    output = rc->has_output ? rc->output : cfg->output;                // mod.rs:220
+    if (output < 0 || output > 3) return set_error(BT_ERR_INVALID_ARG, "invalid output mode");
+    P.max_bounces = (int32_t)(rc->has_max_bounces ? rc->max_bounces : cfg->max_bounces);                 // :223
+    P.max_volume_bounces = (int32_t)(rc->has_max_bounces ? rc->max_bounces : cfg->max_volume_bounces);   // :224 (Q1)
+    P.clip_min = cfg->clip_min;
+    P.clip_max = cfg->clip_max;
+    P.volume_step = rc->has_volume_step ? rc->volume_step : cfg->volume_step;                            // :227
+    if (rc->samples > 0x7fffffffu / (n * n)) return set_error(BT_ERR_INVALID_ARG, "samples * n^2 overflows");
+    P.samples = (int32_t)rc->samples;
+    P.subsample_n = (int32_t)n;
+    P.sample_base = rc->sample_base;
+    P.seed_lo = (uint32_t)seed;
+    P.seed_hi = (uint32_t)(seed >> 32);
+    P.width = width;
+    P.height = height;
+    P.tiles_x = (width + BT_TILE_DIM - 1) / BT_TILE_DIM;
+    P.tiles_y = (height + BT_TILE_DIM - 1) / BT_TILE_DIM;
+    P.rank = 0;
+    P.world = 1;
+    P.sharded = 0;
+    P.counters = s->d_counters;
+    return 0;
+}
+
+int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt_render_config *rc, float *out_device,
+                  uint32_t width, uint32_t height, uint32_t rank, uint32_t world, bool sharded, uint64_t seed,
+                  hipStream_t stream) {
+    if (!s || !cfg || !rc || !out_device) return set_error(BT_ERR_INVALID_ARG, "null argument");
+    if (rc->samples == 0) return BT_DONE;                              // mod.rs:186-188
+    if (world == 0 || rank >= world) return set_error(BT_ERR_INVALID_ARG, "rank/world out of range");
+    int rcode = ensure_device(s);
+    if (rcode) return rcode;
+    BtLaunch P;
+    int output = 0;
+    rcode = fill_launch(s, camera_ref, cfg, rc, width, height, seed, P, output);
+    if (rcode) return rcode;
+    P.rank = rank;
+    P.world = world;
+    P.sharded = sharded ? 1 : 0;
+    P.out = out_device;
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    const uint32_t grid = sharded ? (n_tiles + world - 1) / world : n_tiles;
+
+    BT_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), stream));
+    BT_HIP(hipEventRecord(s->ev_start, stream));
+    BT_HIP(bt_launch_render(&P, output, grid, s->flat.lds_bytes(), stream));
+    BT_HIP(hipEventRecord(s->ev_stop, stream));
+
+    // pixels actually owned by this rank
+    uint64_t pixels = 0;
+    for (uint32_t t = rank; t < n_tiles; t += world) {
+        uint32_t tx = t % P.tiles_x, ty = t / P.tiles_x;
+        uint32_t w = std::min<uint32_t>(BT_TILE_DIM, width - tx * BT_TILE_DIM);
+        uint32_t h = std::min<uint32_t>(BT_TILE_DIM, height - ty * BT_TILE_DIM);
+        pixels += (uint64_t)w * h;
+    }
+    s->last.pixels = pixels;
+    s->last.samples = pixels * (uint64_t)P.samples * (uint64_t)(P.subsample_n * P.subsample_n);
+    s->last.segments = 0;
+    s->last.kernel_ms = 0.0f;
+    s->stats_pending = true;
+    return BT_IN_PROGRESS;                                             // mod.rs:201
+}
+
+} // namespace
+
+extern "C" {
+
+void bt_config_default(bt_config *c) {
+    if (!c) return;
+    c->max_bounces = 8;
+    c->max_volume_bounces = 32;
+    c->clip_min = 0.01f;
+    c->clip_max = 1000.0f;
+    c->volume_step = 0.1f;
+    c->chunks_x = 4;
+    c->chunks_y = 2;
+    c->output = BT_OUTPUT_FULL;
+}
+
+void bt_render_config_default(bt_render_config *r) {
+    if (!r) return;
+    std::memset(r, 0, sizeof *r);
+    r->samples = 64;
+}
+
+const char *bt_last_error(void) { return g_error.c_str(); }
+const char *bt_version(void) { return "bendy-hip 0.1 (gfx950)"; }
+
+bt_scene *bt_scene_from_json(const char *json, size_t len) {
+    if (!json) {
+        set_error(BT_ERR_INVALID_ARG, "null json");
+        return nullptr;
+    }
+    try {
+        std::unique_ptr<bt_scene> s(new bt_scene());
+        s->scene = bt::parse_scene(json, len);
+        return s.release();
+    } catch (const bt::Error &e) {
+        set_error(e.code, e.message);
+    } catch (const std::exception &e) {
+        set_error(BT_ERR_PARSE, e.what());
+    }
+    return nullptr;
+}
+
+bt_scene *bt_scene_load(const char *path) {
+    if (!path) {
+        set_error(BT_ERR_INVALID_ARG, "null path");
+        return nullptr;
+    }
+    try {
+        std::string text = bt::read_scene_file(path);
+        return bt_scene_from_json(text.data(), text.size());
+    } catch (const bt::Error &e) {
+        set_error(e.code, e.message);
+    } catch (const std::exception &e) {
+        set_error(BT_ERR_IO, e.what());
+    }
+    return nullptr;
+}
+
+void bt_scene_free(bt_scene *scene) { delete scene; }
+
+int bt_scene_find_by_tag(const bt_scene *scene, const char *tag, uint64_t *object_ref) {
+    if (!scene || !tag || !object_ref) return set_error(BT_ERR_INVALID_ARG, "null argument");
+    for (const bt::Object &o : scene->scene.objects)
+        if (o.has_tag && o.tag == tag) {
+            *object_ref = o.object_ref;
+            return 0;
+        }
+    return set_error(BT_ERR_INVALID_REF, std::string("no object tagged `") + tag + "`");
+}
+
+int bt_scene_set_camera_aspect(bt_scene *scene, uint64_t camera_ref, float aspect_ratio) {
+    if (!scene) return set_error(BT_ERR_INVALID_ARG, "null scene");
+    int i = scene->scene.object_index(camera_ref);
+    if (i < 0) return set_error(BT_ERR_INVALID_REF, "invalid object ref " + std::to_string(camera_ref));
+    if (scene->scene.objects[i].kind != bt::OBJ_CAMERA) return set_error(BT_ERR_NOT_CAMERA, "expected a camera object");
+    scene->scene.objects[i].aspect_ratio = aspect_ratio;   // read at launch time; device tables unaffected
+    return 0;
+}
+
+int bt_scene_object_count(const bt_scene *scene) { return scene ? (int)scene->scene.objects.size() : 0; }
+int bt_scene_data_count(const bt_scene *scene) { return scene ? (int)scene->scene.data.size() : 0; }
+
+int bt_scene_export_prims(const bt_scene *scene, float *out, int cap) {
+    if (!scene) return set_error(BT_ERR_INVALID_ARG, "null scene");
+    bt_scene *s = const_cast<bt_scene *>(scene);
+    int rc = ensure_flat(s);
+    if (rc) return rc;
+    const size_t words = sizeof(BtPrim) / 4;
+    const int total = (int)(s->flat.prims.size() * words);
+    if (out && cap > 0) std::memcpy(out, s->flat.prims.data(), sizeof(float) * (size_t)std::min(cap, total));
+    return total;
+}
+
+int bt_render_device(bt_scene *scene, uint64_t camera_ref, const bt_config *config, const bt_render_config *render,
+                     float *rgba_device, uint32_t width, uint32_t height, uint64_t seed, void *stream) {
+    return render_common(scene, camera_ref, config, render, rgba_device, width, height, 0, 1, false, seed,
+                         (hipStream_t)stream);
+}
+
+int bt_render(bt_scene *scene, uint64_t camera_ref, const bt_config *config, const bt_render_config *render,
+              float *rgba_host, uint32_t width, uint32_t height, uint64_t seed) {
+    if (!rgba_host) return set_error(BT_ERR_INVALID_ARG, "null buffer");
+    if (render && render->samples == 0) return BT_DONE;
+    if (width == 0 || height == 0) return set_error(BT_ERR_INVALID_ARG, "zero-sized buffer");
+    const size_t bytes = (size_t)width * height * 4 * sizeof(float);
+    float *d = nullptr;
+    BT_HIP(hipMalloc((void **)&d, bytes));
+    hipError_t e = hipMemcpy(d, rgba_host, bytes, hipMemcpyHostToDevice);
+    int rc = BT_ERR_DEVICE;
+    if (e == hipSuccess) {
+        rc = bt_render_device(scene, camera_ref, config, render, d, width, height, seed, nullptr);
+        if (rc >= 0) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(rgba_host, d, bytes, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_error(BT_ERR_DEVICE, hipGetErrorString(e));
+    return rc;
+}
+
+size_t bt_shard_floats(uint32_t width, uint32_t height, uint32_t world) {
+    if (world == 0) return 0;
+    size_t tiles = (size_t)((width + BT_TILE - 1) / BT_TILE) * ((height + BT_TILE - 1) / BT_TILE);
+    size_t per_rank = (tiles + world - 1) / world;
+    return per_rank * BT_TILE * BT_TILE * 4;
+}
+
+int bt_render_shard_device(bt_scene *scene, uint64_t camera_ref, const bt_config *config,
+                           const bt_render_config *render, float *shard_device, uint32_t width, uint32_t height,
+                           uint32_t rank, uint32_t world, uint64_t seed, void *stream) {
+    return render_common(scene, camera_ref, config, render, shard_device, width, height, rank, world, true, seed,
+                         (hipStream_t)stream);
+}
+
+int bt_unshard_device(const float *gathered_device, float *rgba_device, uint32_t width, uint32_t height, uint32_t world,
+                      void *stream) {
+    if (!gathered_device || !rgba_device || world == 0 || width == 0 || height == 0)
+        return set_error(BT_ERR_INVALID_ARG, "invalid argument");
+    uint32_t tiles_x = (width + BT_TILE - 1) / BT_TILE, tiles_y = (height + BT_TILE - 1) / BT_TILE;
+    uint32_t per_rank = (tiles_x * tiles_y + world - 1) / world;
+    BT_HIP(bt_launch_unshard(gathered_device, rgba_device, width, height, tiles_x, tiles_y, world, per_rank,
+                             (hipStream_t)stream));
+    return 0;
+}
+
+int bt_preview_device(const float *rgba_device, uint8_t *rgba8_device, uint32_t width, uint32_t height, uint32_t samples,
+                      int32_t color_space, void *stream) {
+    if (!rgba_device || !rgba8_device || width == 0 || height == 0)
+        return set_error(BT_ERR_INVALID_ARG, "invalid argument");
+    BT_HIP(bt_launch_preview(rgba_device, rgba8_device, width * height, samples, color_space, (hipStream_t)stream));
+    return 0;
+}
+
+int bt_preview(const float *rgba_host, uint8_t *rgba8_host, uint32_t width, uint32_t height, uint32_t samples,
+               int32_t color_space) {
+    if (!rgba_host || !rgba8_host || width == 0 || height == 0) return set_error(BT_ERR_INVALID_ARG, "invalid argument");
+    const size_t n = (size_t)width * height;
+    float *d_in = nullptr;
+    uint8_t *d_out = nullptr;
+    BT_HIP(hipMalloc((void **)&d_in, n * 16));
+    hipError_t e = hipMalloc((void **)&d_out, n * 4);
+    int rc = 0;
+    if (e == hipSuccess) e = hipMemcpy(d_in, rgba_host, n * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) rc = bt_preview_device(d_in, d_out, width, height, samples, color_space, nullptr);
+    if (e == hipSuccess && rc == 0) e = hipMemcpy(rgba8_host, d_out, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return set_error(BT_ERR_DEVICE, hipGetErrorString(e));
+    return rc;
+}
+
+int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {
+    if (!scene || !out) return set_error(BT_ERR_INVALID_ARG, "null argument");
+    if (scene->stats_pending) {
+        BT_HIP(hipEventSynchronize(scene->ev_stop));
+        unsigned long long c[2] = {0, 0};
+        BT_HIP(hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
+        float ms = 0.0f;
+        BT_HIP(hipEventElapsedTime(&ms, scene->ev_start, scene->ev_stop));
+        scene->last.segments = c[0];
+        scene->last.kernel_ms = ms;
+        scene->stats_pending = false;
+    }
+    *out = scene->last;
+    return 0;
+}
+
+} // extern "C"

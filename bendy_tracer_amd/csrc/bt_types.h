@@ -1,0 +1,114 @@
+// bt_types.h -- POD layouts shared by the host scene preparation (bt_scene.cpp) and the
+// HIP kernels (bt_kernels.hip).  Everything here is what actually sits in HBM / LDS.
+#pragma once
+#include <stdint.h>
+
+#define BT_TILE_DIM 16   // pixels per tile edge (== BT_TILE in include/bendy_hip.h)
+
+struct BtV3 { float x, y, z; };
+
+// One row per analytic primitive after flattening: a Cuboid (cuboid.rs:12-15) becomes six
+// rects with the face transform `M * translate(offset)` (cuboid.rs:95) baked in, and every
+// rect carries the inverse of its transform (recomputed per call by the reference,
+// rect.rs:134).  144 bytes, read with wave-uniform (scalar) loads in the intersection loop.
+enum { BT_PRIM_SPHERE = 0, BT_PRIM_RECT = 1, BT_PRIM_CUBOID_FACE = 2 };
+struct BtPrim {
+    int32_t kind;
+    int32_t object;     // object index (ascending ObjectRef) -- `last_object` test, mod.rs:415
+    int32_t material;   // index into materials
+    int32_t volume;     // index into volumes or -1 (sphere.rs:14)
+    // sphere: c = centre (transform.translation), radius.   rect: c = n = M*z (rect.rs:119)
+    BtV3 c;
+    float radius;
+    BtV3 t;             // rect: transform.translation (rect.rs:118)
+    float w_sqr;        // half_width^2  (rect.rs:77)
+    BtV3 icx; float h_sqr;   // inverse transform columns (rect.rs:134) ; half_height^2
+    BtV3 icy; float pad0;
+    BtV3 icz; float pad1;
+    BtV3 it;  float pad2;
+    BtV3 ax;  float pad3;    // Rect.x (rect.rs:17)
+    BtV3 ay;  float pad4;    // Rect.y (rect.rs:18)
+};
+static_assert(sizeof(BtPrim) == 144, "BtPrim must be 144 bytes");
+
+// Per-lane (divergent) lookups after the loop read this 32-byte digest from LDS.
+struct BtPrimLite {
+    BtV3 c;             // sphere centre | rect world normal
+    float radius;
+    int32_t kind_object;  // kind | object << 8
+    int32_t material;
+    int32_t volume;
+    int32_t pad;
+};
+
+enum { BT_MAT_FLAT = 0, BT_MAT_DIFFUSE = 1, BT_MAT_METALLIC = 2, BT_MAT_GLASS = 3, BT_MAT_EMISSIVE = 4 };
+struct BtMaterial {     // material.rs:22-44; 48 bytes
+    int32_t kind;
+    BtV3 albedo;
+    float roughness, ior, inv_ior, pad;
+    BtV3 emitted;       // material.rs:71-79 (albedo or albedo*intensity or 0)
+    float pad1;
+};
+
+struct BtVolume {       // volume.rs:75-82
+    int32_t width, height, depth, offset;   // offset into the density buffer
+    BtV3 size;
+    float pad;
+};
+
+// One entry per LIGHT object (object/mod.rs:17-21), ascending ObjectRef.
+enum { BT_LIGHT_SPHERE = 0, BT_LIGHT_RECT = 1, BT_LIGHT_CUBOID = 2, BT_LIGHT_POINT = 3 };
+struct BtLightFace {    // a rect that can be sampled: rect.rs:82-86
+    BtV3 mcx, mcy, mcz, mt;   // world transform (face transform for cuboids)
+    BtV3 ax, ay;              // Rect.x, Rect.y
+    float half_width, half_height;
+    float scale_x, scale_y;   // Uniform::new_inclusive(-hw,hw) / (-hh,hh) scales
+    float area;               // rect.rs:88-90
+    float pad;
+};
+struct BtLight {
+    int32_t kind;
+    int32_t prim_first, prim_count;   // rows of BtPrim that make up the object
+    int32_t face_first;               // rows of BtLightFace
+    BtV3 centre;                      // sphere / point fallback: transform.translation
+    float radius;
+    float shadow;                     // sphere: PI*r*r (sphere.rs:54)
+    float cum[5];                     // cuboid WeightedIndex cumulative areas (cuboid.rs:49)
+    float total_scale;                // Uniform::new(0, total) scale
+    float pad;
+};
+
+// Kernel launch parameters (by value; they live in the kernarg segment / SGPRs).
+struct BtLaunch {
+    // scene tables
+    const BtPrim *prims;
+    const BtMaterial *materials;
+    const BtVolume *volumes;
+    const BtLight *lights;
+    const BtLightFace *light_faces;
+    const float *density;
+    int32_t n_prims, n_materials, n_volumes, n_lights, n_light_faces, n_density;
+    // root material (mod.rs:429-452), precomputed ColorData of sample_root
+    BtV3 root_color, root_albedo;
+    int32_t root_has_albedo;
+    // camera (mod.rs:248-302)
+    BtV3 cam_cx, cam_cy, cam_cz, cam_t;
+    float yfov, xfov, pixel_width, pixel_height;
+    float jitter_u_lo, jitter_u_scale, jitter_v_lo, jitter_v_scale;
+    int32_t has_focus;
+    float focus, aperture;
+    BtV3 disk_x, disk_y;              // UnitDisk::new(-Z) frame (distr.rs:111-116)
+    float tau_scale, one_scale;       // Uniform::new_inclusive(0,TAU) / (0,1) scales
+    // config (mod.rs:205-230)
+    int32_t max_bounces, max_volume_bounces;
+    float clip_min, clip_max, volume_step;
+    int32_t samples, subsample_n;     // subsample_n >= 1
+    uint32_t sample_base;
+    uint32_t seed_lo, seed_hi;
+    // frame / sharding
+    uint32_t width, height, tiles_x, tiles_y;
+    uint32_t rank, world;
+    int32_t sharded;                  // 0: out = row-major frame; 1: out = this rank's shard
+    float *out;
+    unsigned long long *counters;     // [0] segments, [1] samples
+};

@@ -1,0 +1,155 @@
+/*
+ * bendy_hip.h -- C ABI of libbendy_hip.so, the MI355X (gfx950) implementation of
+ * bendy-tracer's per-pixel / per-sample hot path.
+ *
+ * The reference (soycan-sim/bendy-tracer @ v1) has no FFI surface; its boundary is
+ * the Rust library API that src/main.rs uses.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference tree).
+ * INTEGRATION.md shows the Rust `extern "C"` binding a maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; no exceptions cross the ABI; every
+ * function that can fail returns a negative bt_status and records a message that
+ * bt_last_error() returns (thread-local).  A bt_scene handle is not thread-safe
+ * for concurrent bt_render* calls (same as `&mut Buffer` in the reference).
+ */
+#ifndef BENDY_HIP_H
+#define BENDY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* tracer/mod.rs:159-163 `Status` (>= 0) and error codes (< 0; the reference panics instead). */
+typedef enum {
+    BT_DONE = 0,               /* Status::Done: samples == 0 (mod.rs:186-188) */
+    BT_IN_PROGRESS = 1,        /* Status::InProgress (mod.rs:201) */
+    BT_ERR_INVALID_ARG = -1,
+    BT_ERR_IO = -2,            /* file missing / gzip error (main.rs:93-102) */
+    BT_ERR_PARSE = -3,         /* malformed JSON / unexpected schema (serde error in the reference) */
+    BT_ERR_INVALID_REF = -4,   /* "invalid object ref" / "invalid data ref" (scene/mod.rs:132,136) */
+    BT_ERR_NOT_CAMERA = -5,    /* "expected a camera object" (tracer/mod.rs:246) */
+    BT_ERR_NOT_MATERIAL = -6,  /* "expected material data" / "expected volume data" (mod.rs:464,499) */
+    BT_ERR_NO_LIGHT = -7,      /* Diffuse material but no LIGHT object: Uniform::new(0,0) panics (material.rs:112) */
+    BT_ERR_DEVICE = -8,        /* HIP runtime error / no gfx950 device */
+    BT_ERR_UNSUPPORTED = -9
+} bt_status;
+
+/* tracer/mod.rs:108-115 `Output` */
+typedef enum { BT_OUTPUT_FULL = 0, BT_OUTPUT_ALBEDO = 1, BT_OUTPUT_NORMAL = 2, BT_OUTPUT_DEPTH = 3 } bt_output;
+
+/* tracer/buffer.rs:11-17 `ColorSpace` */
+typedef enum { BT_COLOR_NONE = 0, BT_COLOR_NORMAL = 1, BT_COLOR_LINEAR = 2, BT_COLOR_SRGB = 3 } bt_color_space;
+
+/* tracer/mod.rs:16-26 `Config`; bt_config_default() = Config::DEFAULT (:29-38). */
+typedef struct {
+    uint32_t max_bounces;
+    uint32_t max_volume_bounces;
+    float clip_min;
+    float clip_max;
+    float volume_step;
+    uint32_t chunks_x;         /* kept for API fidelity; the GPU grid does its own tiling */
+    uint32_t chunks_y;
+    int32_t output;            /* bt_output */
+} bt_config;
+
+/* tracer/mod.rs:117-125 `RenderConfig` (Option<T> -> has_* flag + value);
+ * bt_render_config_default() = RenderConfig::DEFAULT (:128-135). */
+typedef struct {
+    uint32_t subsample_n;      /* Subsample: 0 or 1 = None, n >= 2 = Subpixel(n) (:47-52, main.rs:234-237) */
+    uint32_t samples;
+    int32_t has_output;
+    int32_t output;
+    int32_t has_max_bounces;
+    uint32_t max_bounces;
+    int32_t has_max_volume_bounces;
+    uint32_t max_volume_bounces; /* accepted but ignored, exactly like the reference (quirk Q1, mod.rs:224) */
+    int32_t has_volume_step;
+    float volume_step;
+    /* Not in the reference (it seeds from OS entropy, mod.rs:239-242): index of this
+     * call's first sample, so that k progressive calls of 1 sample equal one call of
+     * k samples bit for bit.  Callers normally pass Buffer::samples() / n^2. */
+    uint32_t sample_base;
+} bt_render_config;
+
+/* Work counters of the last render on a scene handle (for the roofline model). */
+typedef struct {
+    uint64_t samples;          /* rays per pixel * pixels rendered by this rank */
+    uint64_t segments;         /* try_hit / try_hit_volume calls (mod.rs:389-427) */
+    uint64_t pixels;
+    float kernel_ms;           /* HIP-event time of the render kernel(s), 0 if not measured */
+} bt_stats;
+
+typedef struct bt_scene bt_scene; /* opaque; replaces `Scene` (scene/mod.rs:84-90) */
+
+void bt_config_default(bt_config *out);                 /* Config::default(), mod.rs:41-45 */
+void bt_render_config_default(bt_render_config *out);   /* RenderConfig::default(), mod.rs:153-157 */
+const char *bt_last_error(void);
+const char *bt_version(void);
+
+/* --- Scene: serde_json::from_reader(GzDecoder) in main.rs:93-102 ------------------- */
+/* `path` ends in .gz -> gzip, else plain JSON (main.rs:97-102).  NULL on error. */
+bt_scene *bt_scene_load(const char *path);
+/* serde_json::from_slice on an in-memory, already decompressed document. */
+bt_scene *bt_scene_from_json(const char *json, size_t len);
+void bt_scene_free(bt_scene *scene);
+/* Scene::find_by_tag (scene/mod.rs:124-129).  Writes the ObjectRef; returns 0, or
+ * BT_ERR_INVALID_REF if no object carries the tag.  When several objects share a tag
+ * the lowest ObjectRef wins (the reference's hash-map order is unspecified). */
+int bt_scene_find_by_tag(const bt_scene *scene, const char *tag, uint64_t *object_ref);
+/* object.as_camera_mut().unwrap().aspect_ratio = a (main.rs:218-223, quirk Q12). */
+int bt_scene_set_camera_aspect(bt_scene *scene, uint64_t camera_ref, float aspect_ratio);
+int bt_scene_object_count(const bt_scene *scene);
+int bt_scene_data_count(const bt_scene *scene);
+/* Flattened primitive table as uploaded to the GPU, for loader cross-checks:
+ * writes up to `cap` floats, returns the number available. */
+int bt_scene_export_prims(const bt_scene *scene, float *out, int cap);
+
+/* --- Tracer::render (tracer/mod.rs:179-202) ----------------------------------------
+ * Adds `samples * n^2` radiance samples per pixel into the RGB channels of `rgba`
+ * (row-major, 4 floats per pixel, alpha untouched: buffer.rs:159-178).  The caller
+ * tracks Buffer::samples += samples * n^2 (mod.rs:199).  `seed` replaces
+ * SmallRng::from_entropy() (mod.rs:239-242).  Returns BT_DONE when samples == 0,
+ * BT_IN_PROGRESS otherwise, < 0 on error.  Nothing is retained after return. */
+
+/* Host buffer (copies H2D, renders on the current device, copies D2H). */
+int bt_render(bt_scene *scene, uint64_t camera_ref, const bt_config *config, const bt_render_config *render,
+              float *rgba_host, uint32_t width, uint32_t height, uint64_t seed);
+
+/* Device-resident buffer; `stream` is a hipStream_t (NULL = default stream).  The call
+ * enqueues work and returns without synchronising. */
+int bt_render_device(bt_scene *scene, uint64_t camera_ref, const bt_config *config, const bt_render_config *render,
+                     float *rgba_device, uint32_t width, uint32_t height, uint64_t seed, void *stream);
+
+/* --- Multi-GPU pixel-tile sharding (new; the reference's only parallelism is rayon
+ * tiles inside one process, tracer/mod.rs:190-197) ---------------------------------
+ * The frame is cut into BT_TILE x BT_TILE pixel tiles, numbered row-major; rank r of
+ * `world` owns tiles r, r+world, r+2*world, ...  A shard holds the rank's tiles
+ * back to back, each tile BT_TILE*BT_TILE*4 floats (padded tiles included), so every
+ * rank's shard has bt_shard_floats() elements and an all-gather concatenates them. */
+#define BT_TILE 16
+size_t bt_shard_floats(uint32_t width, uint32_t height, uint32_t world);
+/* Renders this rank's tiles into `shard_device`, which must hold the rank's
+ * running sums in shard layout (zero + alpha 1 for a fresh frame). */
+int bt_render_shard_device(bt_scene *scene, uint64_t camera_ref, const bt_config *config,
+                           const bt_render_config *render, float *shard_device, uint32_t width, uint32_t height,
+                           uint32_t rank, uint32_t world, uint64_t seed, void *stream);
+/* gathered = `world` shards back to back (the all-gather result) -> row-major frame. */
+int bt_unshard_device(const float *gathered_device, float *rgba_device, uint32_t width, uint32_t height,
+                      uint32_t world, void *stream);
+
+/* --- Buffer::preview (tracer/buffer.rs:117-138): sum/samples -> colour space -> RGBA8 */
+int bt_preview_device(const float *rgba_device, uint8_t *rgba8_device, uint32_t width, uint32_t height,
+                      uint32_t samples, int32_t color_space, void *stream);
+int bt_preview(const float *rgba_host, uint8_t *rgba8_host, uint32_t width, uint32_t height, uint32_t samples,
+               int32_t color_space);
+
+/* Work counters of the most recent bt_render* call on this handle (synchronises). */
+int bt_scene_last_stats(bt_scene *scene, bt_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

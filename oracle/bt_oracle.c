@@ -910,8 +910,8 @@ static colordata_t sample_iterative(chunk_state_t *cs, const ray_t *ray0) {
                 break;
             }
             if (data.has_albedo) {
-                v3 k = vscale(data.albedo.color, material_pdf(material, &m, &data.scatter));
-                beta = vmul(beta, vdivs(k, data.pdf));
+                float weight = material_pdf(material, &m, &data.scatter) / data.pdf;
+                beta = vmul(beta, vscale(data.albedo.color, weight));
                 if (!have_first) { first = data.albedo; have_first = 1; }
             }
             ray = data.scatter;
