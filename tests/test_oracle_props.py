@@ -1,0 +1,88 @@
+"""Properties of the CPU oracle that follow from the reference's algorithm, and the
+committed golden framebuffers (self-generated, see tests/golden/make_golden.py)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from helpers import oracle_render, oracle_scene
+
+_spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+make_golden = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(make_golden)
+
+
+@pytest.mark.parametrize("case", sorted(make_golden.CASES))
+def test_oracle_reproduces_golden(oracle, case):
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    it, seg = make_golden.render_case(case, 0)
+    rec, _ = make_golden.render_case(case, 1)
+    assert seg == int(g["segments"])
+    assert np.array_equal(it, g["iterative"]) and np.array_equal(rec, g["recursive"])
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("scene", 64, 36, 8), ("cornell", 40, 40, 8), ("cornell2", 40, 40, 8),
+                                          ("volume", 48, 32, 8), ("cloud", 48, 32, 8)])
+def test_recursive_and_iterative_forms_agree(oracle, name, w, h, spp):
+    """every recursive return is emitted + k * reflected.color, so the throughput
+    loop is the same estimator; only the rounding of the colour product differs."""
+    rec, seg_r = oracle_render(oracle, name, w, h, spp, recursive=1)
+    it, seg_i = oracle_render(oracle, name, w, h, spp, recursive=0)
+    assert seg_r == seg_i                       # identical geometry / control flow
+    assert np.abs(rec - it).max() / spp <= 1e-5
+    assert np.isfinite(rec).all()
+
+
+def test_result_is_independent_of_tiling_and_threads(oracle):
+    a, _ = oracle_render(oracle, "cornell", 50, 30, 2, threads=1, chunks=(8, 4))
+    b, _ = oracle_render(oracle, "cornell", 50, 30, 2, threads=8, chunks=(3, 5))
+    c, _ = oracle_render(oracle, "cornell", 50, 30, 2, threads=3, chunks=(1, 1))
+    assert np.array_equal(a, b) and np.array_equal(a, c)   # RNG is keyed by (pixel, sample), not by tile
+
+
+def test_progressive_calls_equal_one_call(oracle):
+    """main.rs:245-254 renders 1 sample per call; with sample_base = samples so far the running
+    sums are bit-identical to a single call (the per-pixel `+=` order is the same)."""
+    w, h, total = 40, 24, 4
+    sc, cam = oracle_scene(oracle, "scene", w, h)
+    one, _, _ = oracle.render(sc, cam, oracle.default_config(samples=total), w, h, 11)
+    buf = None
+    for i in range(total):
+        buf, _, _ = oracle.render(sc, cam, oracle.default_config(samples=1, sample_base=i), w, h, 11, rgba=buf)
+    assert np.array_equal(one, buf)
+
+
+def test_seed_changes_the_image_and_same_seed_repeats(oracle):
+    a, _ = oracle_render(oracle, "scene", 48, 27, 2, seed=1)
+    b, _ = oracle_render(oracle, "scene", 48, 27, 2, seed=1)
+    c, _ = oracle_render(oracle, "scene", 48, 27, 2, seed=2)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_subpixel_mode_shoots_n_squared_rays(oracle):
+    a, seg_a = oracle_render(oracle, "scene", 48, 27, 1, n=2)
+    assert seg_a >= 48 * 27 * 4
+    b, _ = oracle_render(oracle, "scene", 48, 27, 4, n=0, seed=99)
+    # same estimator, different sample placement: frame means agree within Monte-Carlo noise
+    assert abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean() < 0.1
+
+
+def test_energy_is_stable_under_more_samples(oracle):
+    lo, _ = oracle_render(oracle, "cornell", 32, 32, 32, seed=3)
+    hi, _ = oracle_render(oracle, "cornell", 32, 32, 64, seed=4)
+    m_lo, m_hi = lo[..., :3].mean() / 32, hi[..., :3].mean() / 64
+    assert abs(m_lo - m_hi) / m_hi < 0.05
+
+
+def test_bounce_limits(oracle):
+    # max_bounces = 0: only camera rays; a Diffuse first hit scatters into `bounce 1 > 0` -> black
+    img, seg = oracle_render(oracle, "cornell", 24, 24, 1, max_bounces=0)
+    assert seg == 24 * 24
+    img8, seg8 = oracle_render(oracle, "cornell", 24, 24, 1, max_bounces=8)
+    assert seg8 > seg and img8[..., :3].sum() > img[..., :3].sum()
+    # volume march is bounded by max_volume_bounces (mod.rs:352-354)
+    _, s_few = oracle_render(oracle, "cloud", 24, 16, 1, max_volume_bounces=2)
+    _, s_many = oracle_render(oracle, "cloud", 24, 16, 1, max_volume_bounces=32)
+    assert s_few < s_many
