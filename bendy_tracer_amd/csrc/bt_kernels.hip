@@ -376,8 +376,11 @@ BT_DEV unsigned long long wave_sum(unsigned long long v) {
 // --------------------------------------------------------------------------------------------
 // The render kernel.  OUTPUT: 0 Full, 1 Albedo, 2 Normal, 3 Depth (tracer/mod.rs:108-115).
 // Block = 256 threads = one 16x16 pixel tile (BT_TILE); wave w covers the 8x8 quadrant w.
+#ifndef BT_WAVES_PER_SIMD
+#define BT_WAVES_PER_SIMD 1
+#endif
 template <int OUTPUT>
-__global__ __launch_bounds__(256) void bt_render_kernel(BtLaunch P) {
+__global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
 
     // ---- stage the per-lane lookup tables in LDS ----
