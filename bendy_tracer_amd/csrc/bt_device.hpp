@@ -1,0 +1,330 @@
+// bt_device.hpp -- device-side building blocks of the render kernel: vector math, the numerics
+// contract's sin/cos and Philox, the samplers of math/distr.rs, and primitive intersection
+// (sphere.rs, rect.rs, cuboid.rs) over the flattened BtPrim table.  Included only by
+// bt_kernels.hip.  Arithmetic follows DESIGN.md's numerics contract so that geometry decisions
+// are bit-identical to the CPU oracle: no FMA contraction, explicit fmaf only in sincos,
+// correctly rounded sqrt / divide (hipcc default), fixed operation order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bt_types.h"
+
+#pragma clang fp contract(off)
+
+#define BT_DEV static __device__ __forceinline__
+
+namespace {
+
+struct V3 { float x, y, z; };
+BT_DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+BT_DEV V3 mk(const BtV3 &a) { return mk(a.x, a.y, a.z); }
+BT_DEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+BT_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+BT_DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+BT_DEV V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+BT_DEV V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+BT_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+BT_DEV float len2(V3 a) { return dot(a, a); }
+BT_DEV V3 normalize(V3 a) { float rl = 1.0f / sqrtf(len2(a)); return a * rl; }
+BT_DEV V3 normalize_or_zero(V3 a) {
+    float rl = 1.0f / sqrtf(len2(a));
+    bool ok = (rl > 0.0f) && (rl < __builtin_inff());
+    return ok ? a * rl : mk(0.0f, 0.0f, 0.0f);
+}
+// M*v with columns cx,cy,cz (glam Affine3A::transform_vector3a)
+BT_DEV V3 xf_vector(V3 cx, V3 cy, V3 cz, V3 v) { return (cx * v.x + cy * v.y) + cz * v.z; }
+
+// ---- sin/cos (numerics contract N5) ------------------------------------------------
+BT_DEV void sincos_bt(float x, float &s, float &c) {
+    float k = __builtin_rintf(x * 0.636619772f);
+    float r = __builtin_fmaf(k, -1.5703125f, x);
+    r = __builtin_fmaf(k, -4.837512969970703125e-4f, r);
+    r = __builtin_fmaf(k, -7.54978995489188e-8f, r);
+    float r2 = r * r;
+    float ps = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    float sn = __builtin_fmaf(ps * r2, r, r);
+    float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2,
+                              4.166664568298827e-2f);
+    float cs = __builtin_fmaf(pc, r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+    int q = ((int)k) & 3;
+    float so = (q & 1) ? cs : sn;
+    float co = (q & 1) ? sn : cs;
+    s = (q & 2) ? -so : so;
+    c = ((q + 1) & 2) ? -co : co;
+}
+
+// ---- Philox4x32-10 (numerics contract N6) --------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+BT_DEV U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    U4 r; r.x = c0; r.y = c1; r.z = c2; r.w = c3;
+    return r;
+}
+BT_DEV float u23(uint32_t x) { return __uint_as_float((x >> 9) | 0x3F800000u) - 1.0f; }
+BT_DEV float u24(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
+BT_DEV bool bernoulli(uint32_t x, float p) { return u24(x) < p; }
+BT_DEV float uniform_sample(uint32_t x, float lo, float scale) { return u23(x) * scale + lo; }
+
+// ---- math/mod.rs ----------------------------------------------------------------------
+BT_DEV float lerpf(float a, float b, float f) { return a + (b - a) * f; }
+BT_DEV V3 reflect(V3 v, V3 n) { return v - n * (2.0f * dot(v, n)); }
+BT_DEV V3 refract(V3 v, V3 n, float ior) {
+    float cos_theta = fminf(dot(-v, n), 1.0f);
+    V3 perp = (n * cos_theta + v) * ior;
+    V3 parallel = n * -sqrtf(fabsf(1.0f - len2(perp)));
+    return perp + parallel;
+}
+BT_DEV float fresnel(V3 v, V3 n, float ior) {
+    float cos_theta = fminf(dot(-v, n), 1.0f);
+    float r0 = (1.0f - ior) / (1.0f + ior);
+    r0 = r0 * r0;
+    float x = 1.0f - cos_theta;
+    float x2 = x * x;
+    return r0 + (1.0f - r0) * ((x2 * x2) * x);
+}
+// glam any_orthonormal_pair (Duff et al.)
+BT_DEV void orthonormal_pair(V3 n, V3 &t1, V3 &t2) {
+    float sign = __builtin_copysignf(1.0f, n.z);
+    float a = -1.0f / (sign + n.z);
+    float b = n.x * n.y * a;
+    t1 = mk(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+    t2 = mk(b, sign + n.y * n.y * a, -n.y);
+}
+
+// ---- math/distr.rs ---------------------------------------------------------------------
+BT_DEV V3 unit_sphere(const BtLaunch &P, uint32_t x1, uint32_t x2) {
+    float r1 = uniform_sample(x1, 0.0f, P.tau_scale), r2 = uniform_sample(x2, 0.0f, P.one_scale);
+    float s, c;
+    sincos_bt(r1, s, c);
+    float x = c * 2.0f * sqrtf(r2 * (1.0f - r2));
+    float y = s * 2.0f * sqrtf(r2 * (1.0f - r2));
+    float z = 1.0f - 2.0f * r2;
+    return mk(x, y, z);
+}
+BT_DEV V3 unit_hemisphere(const BtLaunch &P, V3 normal, uint32_t x1, uint32_t x2) {
+    V3 z_axis = normalize(normal), x_axis, y_axis;
+    orthonormal_pair(z_axis, x_axis, y_axis);
+    float r1 = uniform_sample(x1, 0.0f, P.tau_scale), r2 = uniform_sample(x2, 0.0f, P.one_scale);
+    float s, c;
+    sincos_bt(r1, s, c);
+    float x = c * 2.0f * sqrtf(r2 * (1.0f - r2));
+    float y = s * 2.0f * sqrtf(r2 * (1.0f - r2));
+    float z = 1.0f - r2;
+    return (x_axis * x + y_axis * y) + z_axis * z;
+}
+BT_DEV V3 cosine(const BtLaunch &P, V3 normal, uint32_t x1, uint32_t x2) {
+    V3 z_axis = normalize(normal), x_axis, y_axis;
+    orthonormal_pair(z_axis, x_axis, y_axis);
+    float r1 = uniform_sample(x1, 0.0f, P.tau_scale), r2 = uniform_sample(x2, 0.0f, P.one_scale);
+    float s, c;
+    sincos_bt(r1, s, c);
+    float x = c * sqrtf(r2);
+    float y = s * sqrtf(r2);
+    float z = sqrtf(1.0f - r2);
+    return (x_axis * x + y_axis * y) + z_axis * z;
+}
+
+// ---- LDS scene tables --------------------------------------------------------------------
+struct SceneLds {
+    const BtPrimLite *lite;
+    const BtMaterial *materials;
+    const BtVolume *volumes;
+    const BtLight *lights;
+    const BtLightFace *faces;
+    const float *density;     // LDS copy, or the global buffer when it does not fit
+};
+
+// ---- intersection --------------------------------------------------------------------------
+// Sphere::hit's t selection (sphere.rs:129-145) against the running clip.
+BT_DEV bool sphere_t(V3 o, V3 d, V3 c, float radius, float tmin, float tmax, float &t_out) {
+    V3 oc = o - c;
+    float half_b = dot(oc, d);
+    float cc = len2(oc) - radius * radius;
+    float disc = half_b * half_b - cc;
+    if (!(disc >= 0.0f)) return false;
+    float sqrtd = sqrtf(disc);
+    float t = -half_b - sqrtd;
+    if (t < tmin || t > tmax) {
+        t = -half_b + sqrtd;
+        if (t < tmin || t > tmax) return false;
+    }
+    t_out = t;
+    return true;
+}
+// Rect::hit up to the containment test (rect.rs:110-137); q and p returned for pdf / face.
+BT_DEV bool rect_t(V3 o, V3 d, const BtPrim &R, float tmin, float tmax, bool strict, float &t_out, float &q_out,
+                   float &p_out) {
+    V3 n = mk(R.c);
+    float q = dot(d, n);
+    if (fabsf(q) <= 1e-5f) return false;
+    float p = dot(mk(R.t) - o, n);
+    float t = p / q;
+    if (t < tmin || t > tmax) return false;
+    if (strict && !(t < tmax)) return false;     // Cuboid::hit keeps `manifold.t < t` (cuboid.rs:96)
+    V3 pos = o + d * t;
+    if ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_RECT_AA) {
+        // identity matrix, Rect.x = +-e_u, Rect.y = +-e_v: `M^-1*pos + t'` is pos + t' and each
+        // projection's squared length is the square of one component -- the same float values
+        // the general path below produces (only the sign of exact zeros can differ, and those
+        // are squared), at a third of the instructions.
+        const int u = R.aa_u, v = R.aa_v;
+        float lu = (u == 0 ? pos.x : (u == 1 ? pos.y : pos.z)) + (u == 0 ? R.it.x : (u == 1 ? R.it.y : R.it.z));
+        float lv = (v == 0 ? pos.x : (v == 1 ? pos.y : pos.z)) + (v == 0 ? R.it.x : (v == 1 ? R.it.y : R.it.z));
+        if (!(lu * lu <= R.w_sqr && lv * lv <= R.h_sqr)) return false;
+    } else {
+        V3 local = xf_vector(mk(R.icx), mk(R.icy), mk(R.icz), pos) + mk(R.it);
+        V3 ax = mk(R.ax), ay = mk(R.ay);
+        V3 px = ax * dot(local, ax);
+        V3 py = ay * dot(local, ay);
+        if (!(len2(px) <= R.w_sqr && len2(py) <= R.h_sqr)) return false;
+    }
+    t_out = t;
+    q_out = q;
+    p_out = p;
+    return true;
+}
+
+struct HitRec {
+    float t;
+    int prim;          // -1 = miss
+    bool inside;       // Face::Volume manifold from hit_volumetric (sphere.rs:158-163)
+    bool p_neg;        // rect: p < 0 -> Face::Front (rect.rs:138-142)
+};
+
+// try_hit (mod.rs:389-402) and try_hit_volume (mod.rs:404-427) in one loop: in normal mode
+// last_object is -1 and the clip is [clip_min, clip_max]; while marching it is the marched
+// object and the clip is [0, volume_step].
+BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object) {
+    HitRec h;
+    h.t = tmax;
+    h.prim = -1;
+    h.inside = false;
+    h.p_neg = false;
+    const int n = P.n_prims;
+    for (int i = 0; i < n; ++i) {
+        const BtPrim &R = P.prims[i];           // wave-uniform index -> scalar loads
+        if (R.kind == BT_PRIM_SPHERE) {
+            V3 c = mk(R.c);
+            bool taken = false;
+            if (R.object == last_object) {      // Sphere::hit_volumetric (sphere.rs:150-166)
+                V3 e = (o + d * h.t) - c;
+                if (len2(e) <= R.radius * R.radius) {
+                    h.prim = i;
+                    h.inside = true;
+                    taken = true;
+                }
+            }
+            if (!taken) {
+                float t;
+                if (sphere_t(o, d, c, R.radius, tmin, h.t, t)) {
+                    h.t = t;
+                    h.prim = i;
+                    h.inside = false;
+                }
+            }
+        } else {
+            float t, q, p;
+            if (rect_t(o, d, R, tmin, h.t, (R.kind & BT_PRIM_STRICT) != 0, t, q, p)) {
+                h.t = t;
+                h.prim = i;
+                h.inside = false;
+                h.p_neg = p < 0.0f;
+            }
+        }
+    }
+    return h;
+}
+
+// Object::pdf of a light (object/mod.rs:154-166; sphere.rs:44-61, rect.rs:92-108,
+// cuboid.rs:56-81); 0 when the ray misses it (material.rs:313-316 unwrap_or_default).
+BT_DEV float light_pdf(const BtLaunch &P, const BtLight &Lt, const SceneLds &S, V3 o, V3 d) {
+    if (Lt.kind == BT_LIGHT_SPHERE) {
+        float t;
+        if (!sphere_t(o, d, mk(Lt.centre), Lt.radius, P.clip_min, P.clip_max, t)) return 0.0f;
+        return (t * t) / Lt.shadow;
+    }
+    if (Lt.kind == BT_LIGHT_RECT) {
+        float t, q, p;
+        if (!rect_t(o, d, P.prims[Lt.prim_first], P.clip_min, P.clip_max, false, t, q, p)) return 0.0f;
+        float shadow = S.faces[Lt.face_first].area * fabsf(q);
+        return (t * t) / shadow;
+    }
+    if (Lt.kind == BT_LIGHT_CUBOID) {
+        float best_t = P.clip_max, best_q = 0.0f;
+        int best = -1;
+        for (int f = 0; f < Lt.prim_count; ++f) {
+            float t, q, p;
+            // rect.hit with the object-level clip, then `manifold.t < t` (cuboid.rs:63-75)
+            if (rect_t(o, d, P.prims[Lt.prim_first + f], P.clip_min, P.clip_max, false, t, q, p) && t < best_t) {
+                best_t = t;
+                best_q = q;
+                best = f;
+            }
+        }
+        if (best < 0) return 0.0f;
+        float shadow = S.faces[Lt.face_first + best].area * fabsf(best_q);
+        return (best_t * best_t) / shadow;
+    }
+    return 0.0f;
+}
+
+// Rect::random_point (rect.rs:82-86) on a light face
+BT_DEV V3 face_random_point(const BtLightFace &F, uint32_t x1, uint32_t x2) {
+    float x = uniform_sample(x1, -F.half_width, F.scale_x);
+    float y = uniform_sample(x2, -F.half_height, F.scale_y);
+    V3 local = mk(F.ax) * x + mk(F.ay) * y;
+    return xf_vector(mk(F.mcx), mk(F.mcy), mk(F.mcz), local) + mk(F.mt);
+}
+
+// DensityMap::sample, Trilinear (volume.rs:119-167)
+BT_DEV float density_at(const BtVolume &vol, const float *density, float fx, float fy, float fz) {
+    if (vol.width == 0 || vol.height == 0 || vol.depth == 0) return 0.0f;
+    int x = (int)fx, y = (int)fy, z = (int)fz;
+    x = x < 0 ? 0 : x; y = y < 0 ? 0 : y; z = z < 0 ? 0 : z;
+    if (x >= vol.width || y >= vol.height || z >= vol.depth) return 0.0f;
+    return density[vol.offset + (z * vol.height + y) * vol.width + x];
+}
+BT_DEV float density_sample(const BtVolume &vol, const float *density, V3 coord) {
+    float cx = fminf(fmaxf(coord.x, 0.0f), 1.0f) * vol.size.x;
+    float cy = fminf(fmaxf(coord.y, 0.0f), 1.0f) * vol.size.y;
+    float cz = fminf(fmaxf(coord.z, 0.0f), 1.0f) * vol.size.z;
+    float fx = floorf(cx), fy = floorf(cy), fz = floorf(cz);
+    float ux = ceilf(cx), uy = ceilf(cy), uz = ceilf(cz);
+    float tx = cx - truncf(cx), ty = cy - truncf(cy), tz = cz - truncf(cz);
+    float x0 = density_at(vol, density, fx, fy, fz);
+    float x1 = density_at(vol, density, ux, fy, fz);
+    float y0 = lerpf(x0, x1, tx);
+    x0 = density_at(vol, density, fx, uy, fz);
+    x1 = density_at(vol, density, ux, uy, fz);
+    float y1 = lerpf(x0, x1, tx);
+    float z0 = lerpf(y0, y1, ty);
+    x0 = density_at(vol, density, fx, fy, uz);
+    x1 = density_at(vol, density, ux, fy, uz);
+    y0 = lerpf(x0, x1, tx);
+    x0 = density_at(vol, density, fx, uy, uz);
+    x1 = density_at(vol, density, ux, uy, uz);
+    y1 = lerpf(x0, x1, tx);
+    float z1 = lerpf(y0, y1, ty);
+    return lerpf(z0, z1, tz);
+}
+
+BT_DEV unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+} // namespace

@@ -310,9 +310,22 @@ FlatScene flatten_scene(const Scene &sc) {
         if (vol_of[di] < 0) fail(BT_ERR_NOT_MATERIAL, "expected volume data at ref " + std::to_string(ref));
         return vol_of[di];
     };
-    auto rect_prim = [&](const Rect &r, const Affine &tf, int object, int kind) {
+    // exactly one component is +-1, the others +-0 -> its index, else -1
+    auto unit_axis = [](BtV3 a) -> int {
+        const float c[3] = {a.x, a.y, a.z};
+        int idx = -1;
+        for (int i = 0; i < 3; ++i) {
+            if (c[i] == 1.0f || c[i] == -1.0f) {
+                if (idx >= 0) return -1;
+                idx = i;
+            } else if (c[i] != 0.0f) {
+                return -1;
+            }
+        }
+        return idx;
+    };
+    auto rect_prim = [&](const Rect &r, const Affine &tf, int object, bool strict) {
         BtPrim p{};
-        p.kind = kind;
         p.object = object;
         p.material = material_index(r.material);
         p.volume = -1;
@@ -323,6 +336,16 @@ FlatScene flatten_scene(const Scene &sc) {
         p.ax = r.x; p.ay = r.y;
         p.w_sqr = r.half_width * r.half_width;        // rect.rs:77-78
         p.h_sqr = r.half_height * r.half_height;
+        const bool identity = tf.cx.x == 1.0f && tf.cx.y == 0.0f && tf.cx.z == 0.0f && tf.cy.x == 0.0f &&
+                              tf.cy.y == 1.0f && tf.cy.z == 0.0f && tf.cz.x == 0.0f && tf.cz.y == 0.0f && tf.cz.z == 1.0f;
+        const int au = unit_axis(r.x), av = unit_axis(r.y);
+        int shape = BT_PRIM_RECT;
+        if (identity && au >= 0 && av >= 0) {
+            shape = BT_PRIM_RECT_AA;
+            p.aa_u = au;
+            p.aa_v = av;
+        }
+        p.kind = shape | (strict ? BT_PRIM_STRICT : 0);
         fs.prims.push_back(p);
     };
     auto light_face = [&](const Rect &r, const Affine &tf) {
@@ -350,9 +373,9 @@ FlatScene flatten_scene(const Scene &sc) {
             p.radius = o.radius;
             fs.prims.push_back(p);
         } else if (o.kind == OBJ_RECT) {
-            rect_prim(o.rect, o.world, (int)oi, BT_PRIM_RECT);
+            rect_prim(o.rect, o.world, (int)oi, false);
         } else if (o.kind == OBJ_CUBOID) {
-            for (int f = 0; f < 6; ++f) rect_prim(o.faces[f], translate(o.world, o.face_offset[f]), (int)oi, BT_PRIM_CUBOID_FACE);
+            for (int f = 0; f < 6; ++f) rect_prim(o.faces[f], translate(o.world, o.face_offset[f]), (int)oi, true);
         }
         if (o.flags & 1u) {                           // ObjectFlags::LIGHT, material.rs:106-119
             BtLight l{};

@@ -11,7 +11,12 @@ struct BtV3 { float x, y, z; };
 // rects with the face transform `M * translate(offset)` (cuboid.rs:95) baked in, and every
 // rect carries the inverse of its transform (recomputed per call by the reference,
 // rect.rs:134).  144 bytes, read with wave-uniform (scalar) loads in the intersection loop.
-enum { BT_PRIM_SPHERE = 0, BT_PRIM_RECT = 1, BT_PRIM_CUBOID_FACE = 2 };
+// kind = shape | BT_PRIM_STRICT.  BT_PRIM_RECT_AA is a rect whose transform matrix is exactly the
+// identity and whose x / y axes are signed unit basis vectors: for it `M^-1 * pos + t'` and the two
+// projections of Rect::contains_point (rect.rs:74-80) reduce, bit for bit, to two component adds
+// and two squares (DESIGN.md "Kernel").  BT_PRIM_STRICT marks cuboid faces (`manifold.t < t`,
+// cuboid.rs:96).
+enum { BT_PRIM_SPHERE = 0, BT_PRIM_RECT = 1, BT_PRIM_RECT_AA = 2, BT_PRIM_SHAPE_MASK = 3, BT_PRIM_STRICT = 4 };
 struct BtPrim {
     int32_t kind;
     int32_t object;     // object index (ascending ObjectRef) -- `last_object` test, mod.rs:415
@@ -23,8 +28,8 @@ struct BtPrim {
     BtV3 t;             // rect: transform.translation (rect.rs:118)
     float w_sqr;        // half_width^2  (rect.rs:77)
     BtV3 icx; float h_sqr;   // inverse transform columns (rect.rs:134) ; half_height^2
-    BtV3 icy; float pad0;
-    BtV3 icz; float pad1;
+    BtV3 icy; int32_t aa_u;     // BT_PRIM_RECT_AA: component index of Rect.x
+    BtV3 icz; int32_t aa_v;     // BT_PRIM_RECT_AA: component index of Rect.y
     BtV3 it;  float pad2;
     BtV3 ax;  float pad3;    // Rect.x (rect.rs:17)
     BtV3 ay;  float pad4;    // Rect.y (rect.rs:18)
@@ -35,7 +40,7 @@ static_assert(sizeof(BtPrim) == 144, "BtPrim must be 144 bytes");
 struct BtPrimLite {
     BtV3 c;             // sphere centre | rect world normal
     float radius;
-    int32_t kind_object;  // kind | object << 8
+    int32_t kind_object;  // shape | object << 8
     int32_t material;
     int32_t volume;
     int32_t pad;

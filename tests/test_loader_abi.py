@@ -58,10 +58,23 @@ def _expected_prims(o, sc):
     mats = [i for i in range(sc.c.n_data) if sc._data[i].kind != o.VOLUME]
     vols = [i for i in range(sc.c.n_data) if sc._data[i].kind == o.VOLUME]
 
-    def rect_row(r, tf, oi, kind):
+    def unit_axis(a):
+        c = [a.x, a.y, a.z]
+        ones = [i for i in range(3) if abs(c[i]) == 1.0]
+        return ones[0] if len(ones) == 1 and all(c[i] == 0.0 for i in range(3) if i != ones[0]) else -1
+
+    def rect_row(r, tf, oi, strict):
         inv = o.Affine()
         o.lib().bto_affine_inverse(C.byref(tf), C.byref(inv))
         row = np.zeros(36, dtype=f32)
+        # shape 1 = general rect, 2 = axis-aligned rect (identity matrix, signed unit axes); | 4 = cuboid face
+        identity = [tf.cx.x, tf.cx.y, tf.cx.z, tf.cy.x, tf.cy.y, tf.cy.z, tf.cz.x, tf.cz.y, tf.cz.z] == [1, 0, 0, 0, 1, 0, 0, 0, 1]
+        au, av = unit_axis(r.x), unit_axis(r.y)
+        shape = 2 if (identity and au >= 0 and av >= 0) else 1
+        kind = shape | (4 if strict else 0)
+        if shape == 2:
+            row[19:20].view(np.int32)[:] = au
+            row[23:24].view(np.int32)[:] = av
         row[:4].view(np.int32)[:] = [kind, oi, mats.index(r.material), -1]
         row[4:7] = xf_vector(tf, v(r.z))
         row[8:11] = v(tf.t)
@@ -79,13 +92,13 @@ def _expected_prims(o, sc):
             row[4:7], row[7] = v(ob.world.t), ob.radius
             rows.append(row)
         elif ob.kind == o.RECT:
-            rows.append(rect_row(ob.rect, ob.world, oi, 1))
+            rows.append(rect_row(ob.rect, ob.world, oi, False))
         elif ob.kind == o.CUBOID:
             for f in range(6):
                 tf = o.Affine(ob.world.cx, ob.world.cy, ob.world.cz, ob.world.t)
                 t = xf_vector(ob.world, v(ob.face_offset[f])) + v(ob.world.t)
                 tf.t = o.V3(*[float(x) for x in t])
-                rows.append(rect_row(ob.faces[f], tf, oi, 2))
+                rows.append(rect_row(ob.faces[f], tf, oi, True))
     return np.array(rows, dtype=f32)
 
 
