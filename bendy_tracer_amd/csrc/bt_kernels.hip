@@ -23,6 +23,10 @@
 //   * no MFMA: there is no dense contraction on this path.
 #include "bt_device.hpp"
 
+#ifndef BT_BLOCK_THREADS
+#define BT_BLOCK_THREADS 256
+#endif
+
 namespace {
 
 enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 };
@@ -32,8 +36,10 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // --------------------------------------------------------------------------------------------
 // The render kernel.  OUTPUT: 0 Full, 1 Albedo, 2 Normal, 3 Depth (tracer/mod.rs:108-115).
 // Block = 256 threads = one 16x16 pixel tile (BT_TILE); wave w covers the 8x8 quadrant w.
+// 5 waves per SIMD caps the allocation at 96 VGPRs: 95 used, no scratch, +6-8 % over the
+// unconstrained 104-VGPR build (profiles/r01b/ab_matrix1.log); 6 waves starts to spill.
 #ifndef BT_WAVES_PER_SIMD
-#define BT_WAVES_PER_SIMD 1
+#define BT_WAVES_PER_SIMD 5
 #endif
 template <int OUTPUT>
 __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
@@ -73,13 +79,16 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
     }
 
     // ---- tile / pixel mapping ----
-    const uint32_t tile = P.sharded ? (blockIdx.x * P.world + P.rank) : blockIdx.x;
+    // a workgroup is 1, 2 or 4 waves; four consecutive waves (in launch order) share a 16x16 tile
+    const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t slot = gwave >> 2;                 // tile slot in launch order
+    const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
     const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = gwave & 3;
     const uint32_t lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
     const uint32_t px = tx * BT_TILE_DIM + lx, py = ty * BT_TILE_DIM + ly;
     const bool in_frame = (ty < P.tiles_y) && (px < P.width) && (py < P.height);
-    float *out_px = P.sharded ? P.out + ((size_t)blockIdx.x * (BT_TILE_DIM * BT_TILE_DIM) + ly * BT_TILE_DIM + lx) * 4
+    float *out_px = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + ly * BT_TILE_DIM + lx) * 4
                               : P.out + ((size_t)py * P.width + px) * 4;
 
     const uint32_t pixel_index = py * P.width + px;
@@ -440,7 +449,11 @@ __global__ __launch_bounds__(256) void bt_preview_kernel(const float4 *rgba, uin
 // ---- host-side launchers (called from bt_api.cpp) ---------------------------------------------
 extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream) {
-    dim3 g(grid), b(256);
+    // grid = tiles to render; a tile may be split over several workgroups (BT_BLOCK_THREADS = 64 / 128 /
+    // 256).  Measured on MI355X (profiles/r01b/ab_block.log): no gain from smaller workgroups once the
+    // kernel runs 5 waves/SIMD, and a loss when the LDS tables are large (cloud.json), so 256 it is.
+    const unsigned block = BT_BLOCK_THREADS;
+    dim3 g(grid * (256 / block)), b(block);
     switch (output) {
     case 0: hipLaunchKernelGGL(bt_render_kernel<0>, g, b, lds_bytes, stream, *P); break;
     case 1: hipLaunchKernelGGL(bt_render_kernel<1>, g, b, lds_bytes, stream, *P); break;
