@@ -129,7 +129,7 @@ EXPORTS = [
     "bt_scene_from_json", "bt_scene_free", "bt_scene_find_by_tag", "bt_scene_set_camera_aspect",
     "bt_scene_object_count", "bt_scene_data_count", "bt_scene_export_prims", "bt_render", "bt_render_device",
     "bt_shard_floats", "bt_render_shard_device", "bt_unshard_device", "bt_preview_device", "bt_preview",
-    "bt_scene_last_stats",
+    "bt_scene_last_stats", "bt_scene_default", "bt_scene_to_json", "bt_scene_save", "bt_write_png",
 ]
 
 
@@ -149,6 +149,10 @@ def _load():
     L.bt_scene_from_json.restype = vp
     L.bt_scene_from_json.argtypes = [C.c_char_p, C.c_size_t]
     L.bt_scene_free.argtypes = [vp]
+    L.bt_scene_default.restype = vp
+    L.bt_scene_to_json.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.bt_scene_save.argtypes = [vp, C.c_char_p]
+    L.bt_write_png.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
     L.bt_scene_find_by_tag.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
     L.bt_scene_set_camera_aspect.argtypes = [vp, C.c_uint64, C.c_float]
     L.bt_scene_object_count.argtypes = [vp]
@@ -216,6 +220,22 @@ class Scene:
     def from_json(cls, text):
         data = text.encode() if isinstance(text, str) else bytes(text)
         return cls(lib.bt_scene_from_json(data, len(data)))
+
+    @classmethod
+    def default(cls):
+        """The built-in Cornell scene of main.rs:107-214."""
+        return cls(lib.bt_scene_default())
+
+    def to_json(self) -> str:
+        """serde_json::to_string_pretty(&scene)."""
+        n = _check(lib.bt_scene_to_json(self._h, None, 0))
+        buf = C.create_string_buffer(n + 1)
+        _check(lib.bt_scene_to_json(self._h, buf, n + 1))
+        return buf.value.decode()
+
+    def save(self, path):
+        """Ctrl+K in main.rs:299-313: pretty JSON, gzip when the extension is .gz."""
+        _check(lib.bt_scene_save(self._h, os.fspath(path).encode()))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -380,6 +400,12 @@ class Tracer:
         rc = lib.bt_render_shard_device(scene._h, camera, C.byref(c), C.byref(r), shard.data_ptr(), width, height, rank,
                                         world, seed, torch.cuda.current_stream().cuda_stream)
         return Status(_check(rc))
+
+
+def write_png(path, rgba8):
+    """buffer.preview().save(path) (main.rs:275-298)."""
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    _check(lib.bt_write_png(os.fspath(path).encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[0]))
 
 
 def shard_floats(width, height, world):

@@ -56,6 +56,7 @@ template <class T> struct DeviceArray {
 
 struct bt_scene {
     bt::Scene scene;
+    std::string source;            // the JSON document the scene was parsed from (for bt_scene_save)
     bt::FlatScene flat;
     bool flat_valid = false;
     bool device_valid = false;
@@ -265,6 +266,7 @@ bt_scene *bt_scene_from_json(const char *json, size_t len) {
     try {
         std::unique_ptr<bt_scene> s(new bt_scene());
         s->scene = bt::parse_scene(json, len);
+        s->source.assign(json, len);
         return s.release();
     } catch (const bt::Error &e) {
         set_error(e.code, e.message);
@@ -290,7 +292,51 @@ bt_scene *bt_scene_load(const char *path) {
     return nullptr;
 }
 
+bt_scene *bt_scene_default(void) {
+    std::string text = bt::default_scene_json();
+    return bt_scene_from_json(text.data(), text.size());
+}
+
 void bt_scene_free(bt_scene *scene) { delete scene; }
+
+int bt_scene_to_json(const bt_scene *scene, char *out, size_t cap) {
+    if (!scene) return set_error(BT_ERR_INVALID_ARG, "null scene");
+    try {
+        std::string text = bt::scene_to_pretty_json(scene->scene, scene->source);
+        if (out && cap > 0) {
+            size_t n = std::min(cap - 1, text.size());
+            std::memcpy(out, text.data(), n);
+            out[n] = 0;
+        }
+        return (int)text.size();
+    } catch (const bt::Error &e) {
+        return set_error(e.code, e.message);
+    } catch (const std::exception &e) {
+        return set_error(BT_ERR_PARSE, e.what());
+    }
+}
+
+int bt_scene_save(const bt_scene *scene, const char *path) {
+    if (!scene || !path) return set_error(BT_ERR_INVALID_ARG, "null argument");
+    try {
+        bt::write_text_file(path, bt::scene_to_pretty_json(scene->scene, scene->source));
+        return 0;
+    } catch (const bt::Error &e) {
+        return set_error(e.code, e.message);
+    } catch (const std::exception &e) {
+        return set_error(BT_ERR_IO, e.what());
+    }
+}
+
+int bt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height) {
+    if (!path || !rgba8 || width == 0 || height == 0) return set_error(BT_ERR_INVALID_ARG, "invalid argument");
+    try {
+        bt::write_png(path, rgba8, width, height);
+        return 0;
+    } catch (const bt::Error &e) {
+        return set_error(e.code, e.message);
+    }
+}
 
 int bt_scene_find_by_tag(const bt_scene *scene, const char *tag, uint64_t *object_ref) {
     if (!scene || !tag || !object_ref) return set_error(BT_ERR_INVALID_ARG, "null argument");

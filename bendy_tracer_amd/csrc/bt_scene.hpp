@@ -84,6 +84,14 @@ struct FlatScene {
 };
 FlatScene flatten_scene(const Scene &scene);
 
+// ---- bt_io.cpp: the callers' side ----
+std::string format_f32(float v);
+// pretty JSON of `source` with the scene's camera aspect ratios patched in (main.rs:299-313)
+std::string scene_to_pretty_json(const Scene &scene, const std::string &source);
+void write_text_file(const std::string &path, const std::string &text);   // gzip when the path ends in .gz
+std::string default_scene_json();                                           // main.rs:107-214
+void write_png(const std::string &path, const uint8_t *rgba, uint32_t w, uint32_t h);
+
 // rand 0.8.5 UniformFloat::new / new_inclusive scale
 float uniform_scale(float lo, float hi, bool inclusive);
 // glam Vec3::any_orthonormal_pair

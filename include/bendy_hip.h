@@ -94,7 +94,15 @@ const char *bt_version(void);
 bt_scene *bt_scene_load(const char *path);
 /* serde_json::from_slice on an in-memory, already decompressed document. */
 bt_scene *bt_scene_from_json(const char *json, size_t len);
+/* The scene main.rs builds when the --scene file does not exist (main.rs:107-214). */
+bt_scene *bt_scene_default(void);
 void bt_scene_free(bt_scene *scene);
+/* serde_json::to_writer_pretty(&scene) (main.rs:299-313): writes up to cap-1 bytes + NUL into `out`
+ * (may be NULL) and returns the full length.  bt_scene_save gzips when `path` ends in .gz. */
+int bt_scene_to_json(const bt_scene *scene, char *out, size_t cap);
+int bt_scene_save(const bt_scene *scene, const char *path);
+/* buffer.preview().save(path) (main.rs:275-298): RGBA8 PNG. */
+int bt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height);
 /* Scene::find_by_tag (scene/mod.rs:124-129).  Writes the ObjectRef; returns 0, or
  * BT_ERR_INVALID_REF if no object carries the tag.  When several objects share a tag
  * the lowest ObjectRef wins (the reference's hash-map order is unspecified). */
