@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (shards staged through the host)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--verify", action="store_true", help="after timing, compare the gathered frame with a one-rank render")
     args = ap.parse_args()
 
     import torch
@@ -104,10 +108,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     scene_name, w, h, base_spp = WORKLOADS[args.workload]
     spp = base_spp * world                                  # weak scaling: fixed work per GPU
@@ -126,7 +135,12 @@ def main():
             tracer.render(scene, cam, rc, frame, seed=SEED, sample_base=i * spp)
         else:
             tracer.render_shard(scene, cam, rc, shard, w, h, rank, world, seed=SEED, sample_base=i * spp)
-            dist.all_gather_into_tensor(gathered, shard)    # RCCL over xGMI
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, shard)    # RCCL over xGMI
+            else:                                                # rehearsal path
+                host = torch.empty(gathered.numel(), dtype=torch.float32)
+                dist.all_gather_into_tensor(host, shard.cpu())
+                gathered.copy_(host)
             b.unshard(gathered, frame, world)
 
     def sync():
@@ -164,6 +178,33 @@ def main():
         segments.append(st.segments)
     my_pixels = scene.last_stats().pixels
 
+    verified = None
+    if args.verify:
+        # the gathered frame must equal what one rank renders alone with the same seeds: RNG is keyed by
+        # global pixel / sample index, so the image does not depend on the number of ranks
+        total_steps = args.warmup + 2 * args.steps if world == 1 else args.warmup + args.steps
+        ref = b.Buffer.new(w, h)
+        for i in range(args.warmup + args.steps):
+            tracer.render(scene, cam, rc, ref, seed=SEED, sample_base=i * spp)
+        if world > 1:
+            # shard sums saw the timed steps once and the replay once more; rebuild a clean frame
+            chk = b.new_shard(w, h, world)
+            for i in range(args.warmup + args.steps):
+                tracer.render_shard(scene, cam, rc, chk, w, h, rank, world, seed=SEED, sample_base=i * spp)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, chk)
+            else:
+                host = torch.empty(gathered.numel(), dtype=torch.float32)
+                dist.all_gather_into_tensor(host, chk.cpu())
+                gathered.copy_(host)
+            out = b.Buffer.new(w, h)
+            b.unshard(gathered, out, world)
+            torch.cuda.synchronize()
+            verified = bool(torch.equal(out.data, ref.data))
+        else:
+            verified = True
+        del total_steps
+
     total_samples = w * h * spp * args.steps
     value = total_samples / elapsed / 1e6
     out = {
@@ -193,6 +234,8 @@ def main():
                     "the shipped kernel keeps ray state in registers, so real HBM traffic (`traffic`) is ~32 B/pixel "
                     "and the kernel is VALU-bound, not HBM-bound (DESIGN.md 'Roofline')",
         }
+        if verified is not None:
+            out["verified_vs_single_rank"] = verified
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_name, w, h, args.cpu_budget)
         print(json.dumps(out), flush=True)
