@@ -9,9 +9,11 @@ scene.json.gz, 1920x1080, Subsample::None, Config = main.rs values.  One "step" 
 Tracer::render call that adds `samples` rays per pixel to a frame that stays resident in HBM
 (the reference's progressive pattern, main.rs:245-254; step i uses sample_base = i * samples).
 N = 1: samples = 64 (exactly C3).  N > 1 (weak scaling): samples = 64 * N, the 16x16 pixel tiles
-are dealt round-robin to the ranks, each rank renders its tiles into a shard, one RCCL
-all-gather (over xGMI) collects the shards and an un-permute kernel rebuilds the row-major
-frame -- all inside the timed region.
+are dealt round-robin to the ranks, each rank renders its tiles into a rank-local shard of
+running sums, one RCCL all-gather (over xGMI) collects the shards and an un-permute kernel
+rebuilds the row-major frame.  Shard sums are rank-local, so step i+1's render does not depend on
+step i's exchange: the all-gather + un-permute of step i run on a second HIP stream underneath
+the render of step i+1.  Everything, including the last exchange, is inside the timed region.
 
 One JSON line on rank 0, with `roofline` (SURVEY 8(d) byte model, HIP-event kernel time) and,
 at N = 1, `cpu_baseline` (the CPU oracle -- a C port of the reference algorithm, NOT the Rust
@@ -20,6 +22,7 @@ binary -- timed on the host cores on a bounded sample of the same workload).
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -74,12 +77,58 @@ def cpu_baseline(scene_name, w, h, budget_s=15.0):
 
 def load_pmc_traffic(workload):
     """HBM bytes per launch from a committed rocprofv3 --pmc run (profiles/pmc_traffic.json)."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        d = json.load(open(p))
-        return d.get(workload)
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload)
     except Exception:
         return None
+
+
+class ShardExchange:
+    """Rank-local shard of running sums + the frame exchange of the N > 1 path."""
+
+    def __init__(self, b, torch, dist, w, h, rank, world, backend, overlap):
+        self.b, self.torch, self.dist = b, torch, dist
+        self.w, self.h, self.rank, self.world, self.backend, self.overlap = w, h, rank, world, backend, overlap
+        self.shard = b.new_shard(w, h, world)
+        self.gathered = torch.empty(world * self.shard.numel(), dtype=torch.float32, device="cuda")
+        self.frame = b.Buffer.new(w, h)
+        if overlap:
+            self.staging = [torch.empty_like(self.shard) for _ in range(2)]
+            self.comm = torch.cuda.Stream()
+            self.ev_ready = [torch.cuda.Event() for _ in range(2)]
+            self.ev_free = [torch.cuda.Event() for _ in range(2)]
+
+    def _gather(self, src):
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(self.gathered, src)        # RCCL over xGMI
+        else:                                                            # gloo rehearsal: staged through the host
+            host = self.torch.empty(self.gathered.numel(), dtype=self.torch.float32)
+            self.dist.all_gather_into_tensor(host, src.cpu())
+            self.gathered.copy_(host)
+
+    def exchange(self, i, shard=None, frame=None):
+        """Collects every rank's shard of step i into `frame`; with overlap it runs on the comm stream."""
+        torch = self.torch
+        shard = self.shard if shard is None else shard
+        frame = self.frame if frame is None else frame
+        if not self.overlap:
+            self._gather(shard)
+            self.b.unshard(self.gathered, frame, self.world)
+            return
+        s = i & 1
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.ev_free[s])             # staging[s] was last read by the exchange two steps back
+        self.staging[s].copy_(shard)                 # snapshot: the next render keeps adding into `shard`
+        self.ev_ready[s].record(cur)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.ev_ready[s])
+            self._gather(self.staging[s])
+            self.b.unshard(self.gathered, frame, self.world)
+            self.ev_free[s].record(self.comm)
+
+    def drain(self):
+        if self.overlap:
+            self.torch.cuda.current_stream().wait_stream(self.comm)
 
 
 def main():
@@ -93,7 +142,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (shards staged through the host)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--verify", action="store_true", help="after timing, compare the gathered frame with a one-rank render")
+    ap.add_argument("--no-overlap", action="store_true", help="run the frame exchange on the render stream")
+    ap.add_argument("--verify", action="store_true", help="compare the gathered frame with a one-rank render of the same steps")
     args = ap.parse_args()
 
     import torch
@@ -125,25 +175,22 @@ def main():
     scene.set_camera_aspect(cam, w / h)                     # main.rs:218-223
     tracer = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
     rc = b.RenderConfig.with_samples(spp)
-    frame = b.Buffer.new(w, h)
-    if world > 1:
-        shard = b.new_shard(w, h, world)
-        gathered = torch.empty(world * shard.numel(), dtype=torch.float32, device="cuda")
+    if world == 1:
+        frame = b.Buffer.new(w, h)
+    else:
+        ex = ShardExchange(b, torch, dist, w, h, rank, world, args.backend, overlap=not args.no_overlap)
+        frame = ex.frame
 
     def step(i):
         if world == 1:
             tracer.render(scene, cam, rc, frame, seed=SEED, sample_base=i * spp)
         else:
-            tracer.render_shard(scene, cam, rc, shard, w, h, rank, world, seed=SEED, sample_base=i * spp)
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, shard)    # RCCL over xGMI
-            else:                                                # rehearsal path
-                host = torch.empty(gathered.numel(), dtype=torch.float32)
-                dist.all_gather_into_tensor(host, shard.cpu())
-                gathered.copy_(host)
-            b.unshard(gathered, frame, world)
+            tracer.render_shard(scene, cam, rc, ex.shard, w, h, rank, world, seed=SEED, sample_base=i * spp)
+            ex.exchange(i)
 
     def sync():
+        if world > 1:
+            ex.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -155,7 +202,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()                                   # same stream the kernels are launched on
+        ev[i][0].record()                                   # same stream the render kernel is launched on
         step(args.warmup + i)
         ev[i][1].record()
     sync()
@@ -166,44 +213,27 @@ def main():
         elapsed = float(t.item())
     step_ms = [a.elapsed_time(c) for a, c in ev]
 
-    # segment counts and the library's own HIP-event kernel times: replay the same steps, untimed
+    verified = None
+    if args.verify:
+        # the frame every rank now holds must equal what one rank renders alone with the same seeds: RNG
+        # is keyed by global pixel / sample index, so the image does not depend on the number of ranks
+        ref = b.Buffer.new(w, h)
+        for i in range(args.warmup + args.steps):
+            tracer.render(scene, cam, rc, ref, seed=SEED, sample_base=i * spp)
+        torch.cuda.synchronize()
+        verified = bool(torch.equal(frame.data, ref.data))
+
+    # segment counts and the library's own HIP-event kernel times: replay the same renders, untimed
     kernel_ms, segments = [], []
     for i in range(args.steps):
         if world == 1:
             tracer.render(scene, cam, rc, frame, seed=SEED, sample_base=(args.warmup + i) * spp)
         else:
-            tracer.render_shard(scene, cam, rc, shard, w, h, rank, world, seed=SEED, sample_base=(args.warmup + i) * spp)
+            tracer.render_shard(scene, cam, rc, ex.shard, w, h, rank, world, seed=SEED, sample_base=(args.warmup + i) * spp)
         st = scene.last_stats()
         kernel_ms.append(st.kernel_ms)
         segments.append(st.segments)
     my_pixels = scene.last_stats().pixels
-
-    verified = None
-    if args.verify:
-        # the gathered frame must equal what one rank renders alone with the same seeds: RNG is keyed by
-        # global pixel / sample index, so the image does not depend on the number of ranks
-        total_steps = args.warmup + 2 * args.steps if world == 1 else args.warmup + args.steps
-        ref = b.Buffer.new(w, h)
-        for i in range(args.warmup + args.steps):
-            tracer.render(scene, cam, rc, ref, seed=SEED, sample_base=i * spp)
-        if world > 1:
-            # shard sums saw the timed steps once and the replay once more; rebuild a clean frame
-            chk = b.new_shard(w, h, world)
-            for i in range(args.warmup + args.steps):
-                tracer.render_shard(scene, cam, rc, chk, w, h, rank, world, seed=SEED, sample_base=i * spp)
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, chk)
-            else:
-                host = torch.empty(gathered.numel(), dtype=torch.float32)
-                dist.all_gather_into_tensor(host, chk.cpu())
-                gathered.copy_(host)
-            out = b.Buffer.new(w, h)
-            b.unshard(gathered, out, world)
-            torch.cuda.synchronize()
-            verified = bool(torch.equal(out.data, ref.data))
-        else:
-            verified = True
-        del total_steps
 
     total_samples = w * h * spp * args.steps
     value = total_samples / elapsed / 1e6
@@ -215,10 +245,10 @@ def main():
         "config": {"workload": f"{args.workload}: {scene_name}.json.gz {w}x{h}x{spp}spp Subsample::None, Config=main.rs "
                                f"(max_bounces 8, max_volume_bounces 32, clip 0.01..1000, volume_step 0.1, Output::Full), "
                                f"flat space (the reference has no lens code), seed 0x5EED",
-                   "samples_per_step": w * h * spp, "parallelism": f"tiles{world}" if world > 1 else "single"},
+                   "samples_per_step": w * h * spp,
+                   "parallelism": (f"tiles{world}" + ("" if args.no_overlap else "+overlapped-allgather")) if world > 1 else "single"},
     }
     if rank == 0:
-        import statistics
         k_ms = statistics.mean(kernel_ms)
         seg = statistics.mean(segments)
         alg_bytes = BYTES_PER_SEGMENT * seg + BYTES_PER_PIXEL * my_pixels
@@ -227,7 +257,7 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(args.workload) if world == 1 else None,
             "kernel": "bt_render_kernel<0>", "kernel_ms": round(k_ms, 4),
-            "kernel_ms_timed_region": round(statistics.mean(step_ms), 4),
+            "render_stream_ms_per_step_timed_region": round(statistics.mean(step_ms), 4),
             "segments_per_launch": int(seg), "segments_per_sample": round(seg / (my_pixels * spp), 4),
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "note": "byte model of SURVEY 8(d): 128 B per path segment (wavefront SoA ray state) + 16 B per pixel; "
