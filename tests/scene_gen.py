@@ -41,7 +41,7 @@ def _cuboid(material, hx, hy, hz):
     return {"faces": [[[float(v) for v in off], r] for off, r in faces]}
 
 
-def random_scene(seed, n_objects=8, volume_prob=0.25, focus_prob=0.5, scale_prob=0.3, n_lights=(1, 3)):
+def random_scene(seed, n_objects=8, volume_prob=0.25, focus_prob=0.5, scale_prob=0.3, n_lights=(1, 3), density_dims=(3, 5, 8)):
     rng = np.random.default_rng(seed)
     col = lambda lo=0.1, hi=0.95: dict(zip("rgb", [float(v) for v in rng.uniform(lo, hi, 3)]))
     data = {"0": {"inner": {"Material": {"Flat": {"albedo": {"r": 0.0, "g": 0.0, "b": 0.0}}}}}}
@@ -69,7 +69,7 @@ def random_scene(seed, n_objects=8, volume_prob=0.25, focus_prob=0.5, scale_prob
     light_mat = add_data({"Material": {"Emissive": {"albedo": col(0.7, 1.0), "intensity": float(rng.uniform(5, 20))}}})
 
     def density_map():
-        n = int(rng.choice([3, 5, 8]))
+        n = int(rng.choice(list(density_dims)))
         buf = rng.uniform(0, 1, n * n * n).astype(np.float32)
         buf[rng.uniform(size=buf.size) < 0.5] = 0.0
         buf *= np.float32(rng.choice([0.5, 3.0, 12.0]))      # up to density*step >= 1

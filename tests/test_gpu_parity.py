@@ -325,3 +325,37 @@ def test_random_scenes_bit_exact(bendy, oracle, seed):
     got = buf.numpy()
     assert gs.last_stats().segments == seg
     assert np.array_equal(got, it, equal_nan=True)
+
+
+def _compare_json_scene(bendy, oracle, txt, w, h, spp, seed=3):
+    import torch
+    gs = bendy.Scene.from_json(txt); cam = gs.find_by_tag("camera"); gs.set_camera_aspect(cam, w / h)
+    buf = bendy.Buffer.new(w, h)
+    bendy.Tracer.new().render(gs, cam, bendy.RenderConfig.with_samples(spp), buf, seed=seed)
+    torch.cuda.synchronize()
+    osc = oracle.Scene(json.loads(txt)); ocam = osc.find_by_tag("camera"); osc.set_camera_aspect(ocam, w / h)
+    it, _, seg = oracle.render(osc, ocam, oracle.default_config(samples=spp, recursive=0), w, h, seed, nthreads=8)
+    assert gs.last_stats().segments == seg
+    assert np.array_equal(buf.numpy(), it, equal_nan=True)
+    return gs
+
+
+def test_scene_without_primitives(bendy, oracle):
+    """Only a camera: every ray goes to sample_root (mod.rs:429-452); empty device tables."""
+    doc = json.loads(flat_scene_json())
+    del doc["objects"]["collection"]["1"]
+    gs = _compare_json_scene(bendy, oracle, json.dumps(doc), 40, 24, 3)
+    assert gs.export_prims().shape[0] == 0
+
+
+def test_density_map_larger_than_the_lds_budget(bendy, oracle):
+    """A 24^3 density map (55 KB) stays in global memory instead of LDS; same pixels."""
+    from scene_gen import random_scene
+    for seed in (100, 101, 102):
+        _compare_json_scene(bendy, oracle, random_scene(seed, n_objects=6, volume_prob=1.0, density_dims=(24,)), 64, 40, 4)
+
+
+def test_many_objects(bendy, oracle):
+    from scene_gen import random_scene
+    gs = _compare_json_scene(bendy, oracle, random_scene(7, n_objects=60, n_lights=(4, 4)), 64, 40, 2)
+    assert gs.export_prims().shape[0] > 100
