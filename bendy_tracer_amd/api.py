@@ -129,7 +129,7 @@ EXPORTS = [
     "bt_scene_from_json", "bt_scene_free", "bt_scene_find_by_tag", "bt_scene_set_camera_aspect",
     "bt_scene_object_count", "bt_scene_data_count", "bt_scene_export_prims", "bt_render", "bt_render_device",
     "bt_shard_floats", "bt_render_shard_device", "bt_unshard_device", "bt_preview_device", "bt_preview",
-    "bt_scene_last_stats", "bt_scene_default", "bt_scene_to_json", "bt_scene_save", "bt_write_png",
+    "bt_scene_last_stats", "bt_set_kernel_variant", "bt_scene_default", "bt_scene_to_json", "bt_scene_save", "bt_write_png",
 ]
 
 
@@ -400,6 +400,11 @@ class Tracer:
         rc = lib.bt_render_shard_device(scene._h, camera, C.byref(c), C.byref(r), shard.data_ptr(), width, height, rank,
                                         world, seed, torch.cuda.current_stream().cuda_stream)
         return Status(_check(rc))
+
+
+def set_kernel_variant(name):
+    """"default" | "lanes" | "sorted": which of the two bit-identical render kernels runs (A/B measurements)."""
+    _check(lib.bt_set_kernel_variant({"default": 0, "lanes": 1, "sorted": 2}[name]))
 
 
 def write_png(path, rgba8):

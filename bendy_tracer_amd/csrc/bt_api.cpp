@@ -16,6 +16,9 @@
 #pragma STDC FP_CONTRACT OFF
 
 extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t bt_launch_render_sorted(const BtLaunch *P, int output, unsigned grid, size_t scene_lds_bytes,
+                                              hipStream_t stream);
+extern "C" size_t bt_sorted_state_bytes(int output);
 extern "C" hipError_t bt_launch_unshard(const float *gathered, float *frame, uint32_t width, uint32_t height,
                                         uint32_t tiles_x, uint32_t tiles_y, uint32_t world, uint32_t tiles_per_rank,
                                         hipStream_t stream);
@@ -27,6 +30,7 @@ static_assert(BT_TILE == BT_TILE_DIM, "public and device tile sizes must agree")
 namespace {
 
 thread_local std::string g_error;
+int g_kernel_variant = 0;          // bt_set_kernel_variant: 0 = default (BT_KERNEL_LANES unless $BT_KERNEL says otherwise)
 int set_error(int code, const std::string &msg) {
     g_error = msg;
     return code;
@@ -214,7 +218,23 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
 
     BT_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), stream));
     BT_HIP(hipEventRecord(s->ev_start, stream));
-    BT_HIP(bt_launch_render(&P, output, grid, s->flat.lds_bytes(), stream));
+    // Two bit-identical kernels: the regrouping one (bt_kernels_sorted.hip, path state in LDS, lanes
+    // re-sorted by event kind every iteration) and the lane-owns-pixel one (bt_kernels.hip).  The
+    // sorted kernel packs bounce counters into 8 bits and needs ~25 KB of LDS per workgroup on top
+    // of the scene tables; BT_KERNEL=lanes|sorted overrides the choice (A/B runs).
+    static const int env_variant = [] {
+        const char *e = getenv("BT_KERNEL");
+        if (!e) return 0;
+        return std::strcmp(e, "lanes") == 0 ? BT_KERNEL_LANES : (std::strcmp(e, "sorted") == 0 ? BT_KERNEL_SORTED : 0);
+    }();
+    const int variant = g_kernel_variant ? g_kernel_variant : env_variant;
+    const bool can_sort = P.max_bounces < 250 && P.max_volume_bounces < 250 &&
+                          s->flat.lds_bytes() + bt_sorted_state_bytes(output) <= 64 * 1024;
+    const bool use_sorted = can_sort && variant == BT_KERNEL_SORTED;
+    if (use_sorted)
+        BT_HIP(bt_launch_render_sorted(&P, output, grid, s->flat.lds_bytes(), stream));
+    else
+        BT_HIP(bt_launch_render(&P, output, grid, s->flat.lds_bytes(), stream));
     BT_HIP(hipEventRecord(s->ev_stop, stream));
 
     // pixels actually owned by this rank
@@ -256,6 +276,13 @@ void bt_render_config_default(bt_render_config *r) {
 }
 
 const char *bt_last_error(void) { return g_error.c_str(); }
+
+int bt_set_kernel_variant(int variant) {
+    if (variant != BT_KERNEL_DEFAULT && variant != BT_KERNEL_LANES && variant != BT_KERNEL_SORTED)
+        return set_error(BT_ERR_INVALID_ARG, "unknown kernel variant");
+    g_kernel_variant = variant;
+    return 0;
+}
 const char *bt_version(void) { return "bendy-hip 0.1 (gfx950)"; }
 
 bt_scene *bt_scene_from_json(const char *json, size_t len) {

@@ -154,6 +154,14 @@ int bt_preview_device(const float *rgba_device, uint8_t *rgba8_device, uint32_t 
 int bt_preview(const float *rgba_host, uint8_t *rgba8_host, uint32_t width, uint32_t height, uint32_t samples,
                int32_t color_space);
 
+/* Two bit-identical implementations of the render kernel exist (DESIGN.md "Kernel"):
+ * BT_KERNEL_LANES  -- a lane owns a pixel, path state in registers (default, fastest measured);
+ * BT_KERNEL_SORTED -- path state in LDS, the workgroup re-sorts its 256 paths by pending event kind
+ *                     every iteration (ballot / prefix-sum compaction).  Process-wide switch for A/B
+ *                     measurements; BT_KERNEL_DEFAULT restores the built-in choice. */
+enum { BT_KERNEL_DEFAULT = 0, BT_KERNEL_LANES = 1, BT_KERNEL_SORTED = 2 };
+int bt_set_kernel_variant(int variant);
+
 /* Work counters of the most recent bt_render* call on this handle (synchronises). */
 int bt_scene_last_stats(bt_scene *scene, bt_stats *out);
 

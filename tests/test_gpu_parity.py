@@ -355,6 +355,37 @@ def test_density_map_larger_than_the_lds_budget(bendy, oracle):
         _compare_json_scene(bendy, oracle, random_scene(seed, n_objects=6, volume_prob=1.0, density_dims=(24,)), 64, 40, 4)
 
 
+# ---- the regrouping kernel (bt_kernels_sorted.hip) is bit-identical to the default one ---------------------
+@pytest.fixture
+def sorted_kernel(bendy):
+    bendy.set_kernel_variant("sorted")
+    yield
+    bendy.set_kernel_variant("default")
+
+
+@pytest.mark.parametrize("case", sorted(_golden_cases()))
+def test_sorted_kernel_matches_golden(bendy, sorted_kernel, case):
+    name, w, h, spp, n, out = _golden_cases()[case]
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    buf, stats, _ = gpu_render(bendy, name, w, h, spp, n=n, output=out)
+    assert stats.segments == int(g["segments"]) and np.array_equal(buf.numpy(), g["iterative"])
+
+
+@pytest.mark.parametrize("seed", [0, 3, 5, 9, 13, 17, 18, 19, 22])
+def test_sorted_kernel_random_scenes(bendy, oracle, sorted_kernel, seed):
+    test_random_scenes_bit_exact(bendy, oracle, seed)
+
+
+def test_sorted_kernel_full_size_equals_default(bendy, sorted_kernel):
+    a, sa, _ = gpu_render(bendy, "scene", 1920, 1080, 64)
+    c, sc_, _ = gpu_render(bendy, "cloud", 480, 270, 16)
+    bendy.set_kernel_variant("lanes")
+    b_, sb, _ = gpu_render(bendy, "scene", 1920, 1080, 64)
+    d, sd, _ = gpu_render(bendy, "cloud", 480, 270, 16)
+    assert sa.segments == sb.segments and np.array_equal(a.numpy(), b_.numpy())
+    assert sc_.segments == sd.segments and np.array_equal(c.numpy(), d.numpy())
+
+
 def test_many_objects(bendy, oracle):
     from scene_gen import random_scene
     gs = _compare_json_scene(bendy, oracle, random_scene(7, n_objects=60, n_lights=(4, 4)), 64, 40, 2)

@@ -12,7 +12,7 @@ import csv, collections
 agg=collections.defaultdict(list)
 for g in 'ab':
     for r in csv.DictReader(open('$OUT/%s/pmc_counter_collection.csv'%g)):
-        if 'bt_render_kernel' in r['Kernel_Name']:
+        if 'bt_render' in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
 m={k:sum(v)/len(v) for k,v in agg.items()}
 for k in sorted(m): print(f'{k:28s} {m[k]:.4g}')
