@@ -125,7 +125,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = [
-    "bt_config_default", "bt_render_config_default", "bt_last_error", "bt_version", "bt_scene_load",
+    "bt_config_default", "bt_render_config_default", "bt_last_error", "bt_last_error_code", "bt_version", "bt_scene_load",
     "bt_scene_from_json", "bt_scene_free", "bt_scene_find_by_tag", "bt_scene_set_camera_aspect",
     "bt_scene_object_count", "bt_scene_data_count", "bt_scene_export_prims", "bt_render", "bt_render_device",
     "bt_shard_floats", "bt_render_shard_device", "bt_unshard_device", "bt_preview_device", "bt_preview",
@@ -205,16 +205,12 @@ class Scene:
 
     def __init__(self, handle):
         if not handle:
-            raise BendyError(-3, lib.bt_last_error().decode("utf-8", "replace"))
+            raise BendyError(lib.bt_last_error_code(), lib.bt_last_error().decode("utf-8", "replace"))
         self._h = C.c_void_p(handle)
 
     @classmethod
     def load(cls, path):
-        h = lib.bt_scene_load(os.fspath(path).encode())
-        if not h:
-            msg = lib.bt_last_error().decode("utf-8", "replace")
-            raise BendyError(-2 if "cannot open" in msg or "gzip" in msg else -3, msg)
-        return cls(h)
+        return cls(lib.bt_scene_load(os.fspath(path).encode()))
 
     @classmethod
     def from_json(cls, text):

@@ -31,8 +31,10 @@ namespace {
 
 thread_local std::string g_error;
 int g_kernel_variant = 0;          // bt_set_kernel_variant: 0 = default (BT_KERNEL_LANES unless $BT_KERNEL says otherwise)
+thread_local int g_error_code = 0;
 int set_error(int code, const std::string &msg) {
     g_error = msg;
+    g_error_code = code;
     return code;
 }
 
@@ -276,6 +278,7 @@ void bt_render_config_default(bt_render_config *r) {
 }
 
 const char *bt_last_error(void) { return g_error.c_str(); }
+int bt_last_error_code(void) { return g_error_code; }
 
 int bt_set_kernel_variant(int variant) {
     if (variant != BT_KERNEL_DEFAULT && variant != BT_KERNEL_LANES && variant != BT_KERNEL_SORTED)

@@ -420,9 +420,40 @@ __global__ __launch_bounds__(256) void bt_unshard_kernel(const float4 *gathered,
 
 // Buffer::preview (buffer.rs:117-138): mean -> colour space -> (x * 255) as u8.
 namespace {
+// numerics contract N9: x^(1/2.4) = exp2(log2(x) / 2.4), same polynomials as the oracle
+BT_DEV float log2_bt(float x) {
+    const uint32_t xi = __float_as_uint(x);
+    int e = (int)((xi >> 23) & 0xffu) - 127;
+    float m = __uint_as_float((xi & 0x7fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float t = m - 1.0f;
+    const float s = t / (2.0f + t), s2 = s * s;
+    float p = __builtin_fmaf(s2, 0.0909090909f, 0.1111111111f);
+    p = __builtin_fmaf(p, s2, 0.1428571429f);
+    p = __builtin_fmaf(p, s2, 0.2f);
+    p = __builtin_fmaf(p, s2, 0.3333333333f);
+    const float ln = __builtin_fmaf(p * s2, s, s) * 2.0f;
+    return __builtin_fmaf(ln, 1.4426950408889634f, (float)e);
+}
+BT_DEV float exp2_bt(float y) {
+    const float k = __builtin_rintf(y), r = y - k;
+    const float z = r * 0.6931471805599453f;
+    float p = __builtin_fmaf(z, 1.984126984e-4f, 1.388888889e-3f);
+    p = __builtin_fmaf(p, z, 8.333333333e-3f);
+    p = __builtin_fmaf(p, z, 4.166666667e-2f);
+    p = __builtin_fmaf(p, z, 1.666666667e-1f);
+    p = __builtin_fmaf(p, z, 0.5f);
+    p = __builtin_fmaf(p, z, 1.0f);
+    p = __builtin_fmaf(p, z, 1.0f);
+    const int ki = (int)k;
+    if (ki < -126) return 0.0f;
+    if (ki > 127) return __builtin_inff();
+    return p * __uint_as_float((uint32_t)(ki + 127) << 23);
+}
 BT_DEV float linear_to_srgb(float x) {              // color.rs:14-20
     if (x <= 0.0031308f) return 12.92f * x;
-    return 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
+    if (!(x < 3.0e38f)) return x;
+    return 1.055f * exp2_bt(log2_bt(x) * (1.0f / 2.4f)) - 0.055f;
 }
 BT_DEV uint32_t f32_to_u8(float x) {                // color.rs:22-24 (saturating `as u8`)
     float v = x * 255.0f;

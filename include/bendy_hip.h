@@ -87,6 +87,7 @@ typedef struct bt_scene bt_scene; /* opaque; replaces `Scene` (scene/mod.rs:84-9
 void bt_config_default(bt_config *out);                 /* Config::default(), mod.rs:41-45 */
 void bt_render_config_default(bt_render_config *out);   /* RenderConfig::default(), mod.rs:153-157 */
 const char *bt_last_error(void);
+int bt_last_error_code(void);      /* bt_status of the last failure on this thread (for NULL-returning constructors) */
 const char *bt_version(void);
 
 /* --- Scene: serde_json::from_reader(GzDecoder) in main.rs:93-102 ------------------- */

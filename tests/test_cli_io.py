@@ -141,6 +141,47 @@ def test_cli_renders_like_the_library(bendy, tmp_path, output, scene):
     assert np.array_equal(back.export_prims().view(np.uint32), sc.export_prims().view(np.uint32))
 
 
+def _build_hpp_smoke(tmp_path):
+    exe = tmp_path / "hpp_smoke"
+    libdir = os.path.join(ROOT, "bendy_tracer_amd")
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "hpp_smoke.cpp"), "-L" + libdir, "-lbendy_hip",
+                           "-Wl,-rpath," + libdir, "-o", str(exe)])
+    return exe
+
+
+def test_cpp_header_mirror_without_gpu(tmp_path):
+    """include/bendy_tracer.hpp (Scene / Tracer / Buffer / RenderConfig ...) compiles with plain g++ against
+    the C ABI; defaults, loader errors and Status::Done work without a device, render fails loudly."""
+    import torch
+    exe = _build_hpp_smoke(tmp_path)
+    r = subprocess.run([str(exe), scene_path("scene"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 42 and "render error -8" in r.stdout      # BT_ERR_DEVICE, no CPU fallback
+
+
+@pytest.mark.gpu
+def test_cpp_header_mirror_renders_like_python(bendy, tmp_path):
+    import torch
+    exe = _build_hpp_smoke(tmp_path)
+    out = tmp_path / "o.bin"
+    r = subprocess.run([str(exe), scene_path("scene"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok samples=8" in r.stdout, r.stdout + r.stderr
+    w, h = 48, 27
+    raw = np.fromfile(out, dtype=np.uint8)
+    sums = raw[:w * h * 16].view(np.float32).reshape(h, w, 4)
+    rgba8 = raw[w * h * 16:].reshape(h, w, 4)
+    sc = bendy.Scene.load(scene_path("scene")); cam = sc.find_by_tag("camera"); sc.set_camera_aspect(cam, w / h)
+    buf = bendy.Buffer.new(w, h, bendy.ColorSpace.SRgb)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    while buf.samples < 8:
+        tr.render(sc, cam, bendy.RenderConfig.with_samples_subsample(1, bendy.Subsample(2)), buf, seed=99)
+    torch.cuda.synchronize()
+    assert np.array_equal(sums, buf.numpy()) and np.array_equal(rgba8, buf.preview())
+
+
 @pytest.mark.gpu
 def test_cli_screenshot_without_extension_uses_render_png(tmp_path):
     d = tmp_path / "shots"

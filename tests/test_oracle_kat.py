@@ -292,7 +292,20 @@ def test_preview_resolve(oracle):
     knee = 12.92 * 0.0031308
     assert srgb[0, 6, 0] == int(knee * 255)
     assert srgb[0, 5, 0] == int((1.055 * 0.5 ** (1 / 2.4) - 0.055) * 255)  # 187
-    assert srgb[0, 2, 0] == 255 or srgb[0, 2, 0] == 254
+    assert srgb[0, 2, 0] == 254 or srgb[0, 2, 0] == 255
+
+
+def test_srgb_transfer_tracks_libm(oracle):
+    """Numerics contract N9: the oracle's own x^(1/2.4) stays within 1 LSB of the exact transfer."""
+    xs = np.linspace(0.0, 1.2, 4096).astype(np.float32)
+    rgba = np.zeros((1, xs.size, 4), dtype=np.float32)
+    rgba[0, :, 0] = xs
+    rgba[..., 3] = 1.0
+    got = oracle.preview(rgba, 1, 3)[0, :, 0].astype(np.int32)
+    x64 = xs.astype(np.float64)
+    exact = np.where(x64 <= 0.0031308, 12.92 * x64, 1.055 * np.power(x64, 1 / 2.4) - 0.055)
+    want = np.clip(np.floor(exact * 255.0), 0, 255).astype(np.int32)
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
 
 
 # ---- KAT 11: loader (SURVEY Appendix A) --------------------------------------------------------------
