@@ -121,12 +121,18 @@ class _CRenderConfig(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("pixels", C.c_uint64), ("kernel_ms", C.c_float)]
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("pixels", C.c_uint64), ("kernel_ms", C.c_float),
+                ("lens_steps", C.c_uint64)]
+
+
+class _CLens(C.Structure):
+    _fields_ = [("centre", C.c_float * 3), ("rs", C.c_float), ("step", C.c_float), ("radius", C.c_float),
+                ("max_steps", C.c_uint32)]
 
 
 EXPORTS = [
     "bt_config_default", "bt_render_config_default", "bt_last_error", "bt_last_error_code", "bt_version", "bt_scene_load",
-    "bt_scene_from_json", "bt_scene_free", "bt_scene_find_by_tag", "bt_scene_set_camera_aspect",
+    "bt_scene_from_json", "bt_scene_free", "bt_scene_find_by_tag", "bt_scene_set_camera_aspect", "bt_scene_set_lens",
     "bt_scene_object_count", "bt_scene_data_count", "bt_scene_export_prims", "bt_render", "bt_render_device",
     "bt_shard_floats", "bt_render_shard_device", "bt_unshard_device", "bt_preview_device", "bt_preview",
     "bt_scene_last_stats", "bt_set_kernel_variant", "bt_scene_default", "bt_scene_to_json", "bt_scene_save", "bt_write_png",
@@ -155,6 +161,7 @@ def _load():
     L.bt_write_png.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
     L.bt_scene_find_by_tag.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
     L.bt_scene_set_camera_aspect.argtypes = [vp, C.c_uint64, C.c_float]
+    L.bt_scene_set_lens.argtypes = [vp, C.POINTER(_CLens)]
     L.bt_scene_object_count.argtypes = [vp]
     L.bt_scene_data_count.argtypes = [vp]
     L.bt_scene_export_prims.argtypes = [vp, fp, C.c_int]
@@ -248,6 +255,14 @@ class Scene:
     def set_camera_aspect(self, camera_ref, aspect_ratio):
         """main.rs:218-223."""
         _check(lib.bt_scene_set_camera_aspect(self._h, camera_ref, aspect_ratio))
+
+    def set_lens(self, centre, rs, step, radius, max_steps=4096):
+        """EXTENSION, not in the reference (include/bendy_hip.h `bt_lens`): bend rays around a point mass."""
+        lens = _CLens((C.c_float * 3)(*[float(v) for v in centre]), rs, step, radius, max_steps)
+        _check(lib.bt_scene_set_lens(self._h, C.byref(lens)))
+
+    def clear_lens(self):
+        _check(lib.bt_scene_set_lens(self._h, None))
 
     @property
     def object_count(self):

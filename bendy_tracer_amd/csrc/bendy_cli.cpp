@@ -7,7 +7,8 @@
 // 1 x subsample^2 rays per pixel per iteration until --samples is reached, main.rs:245-254), keeps
 // the frame in HBM, prints what the window title would show (main.rs:352-388) and then does what
 // Ctrl+P does (preview -> PNG, main.rs:275-298) and, with --save-scene, what Ctrl+K does
-// (pretty JSON, gzip for .gz, main.rs:299-313).  Extra flags: --seed, --save-scene, --device, --quiet.
+// (pretty JSON, gzip for .gz, main.rs:299-313).  Extra flags: --seed, --save-scene, --device, --quiet, and
+// --lens x,y,z,rs,step,radius[,max_steps] for the gravitational-lens EXTENSION (not in the reference; bt_lens).
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 
@@ -68,13 +69,16 @@ struct Args {
     std::string save_scene;
     int device = 0;
     bool quiet = false;
+    bool has_lens = false;
+    bt_lens lens{};
 };
 
 void usage() {
     std::fprintf(stderr,
                  "usage: bendy-tracer-hip --output <full|albedo|normal> [--width 768] [--height 512] [--samples 64]\n"
                  "       [--subsample 2] [--screenshot screenshots/render.png] [--scene scene.json]\n"
-                 "       [--seed N] [--save-scene PATH] [--device N] [--quiet]\n");
+                 "       [--seed N] [--save-scene PATH] [--device N] [--quiet]\n"
+                 "       [--lens x,y,z,rs,step,radius[,max_steps]]   (extension: not in the reference)\n");
 }
 
 Args parse(int argc, char **argv) {
@@ -100,6 +104,16 @@ Args parse(int argc, char **argv) {
         else if (k == "--save-scene") a.save_scene = val();
         else if (k == "--device") a.device = std::atoi(val().c_str());
         else if (k == "--quiet") a.quiet = true;
+        else if (k == "--lens") {
+            const std::string spec = val();
+            float f[7] = {0, 0, 0, 0, 0, 0, 4096};
+            int n = std::sscanf(spec.c_str(), "%f,%f,%f,%f,%f,%f,%f", &f[0], &f[1], &f[2], &f[3], &f[4], &f[5], &f[6]);
+            if (n < 6) die("--lens expects x,y,z,rs,step,radius[,max_steps]");
+            a.lens.centre[0] = f[0]; a.lens.centre[1] = f[1]; a.lens.centre[2] = f[2];
+            a.lens.rs = f[3]; a.lens.step = f[4]; a.lens.radius = f[5];
+            a.lens.max_steps = (uint32_t)f[6];
+            a.has_lens = true;
+        }
         else if (k == "--help" || k == "-h") { usage(); std::exit(0); }
         else { usage(); die("unknown argument " + k); }
     }
@@ -134,6 +148,7 @@ int main(int argc, char **argv) {
     uint64_t camera = 0;
     check(bt_scene_find_by_tag(scene, "camera", &camera), "find_by_tag(\"camera\")");          // main.rs:216
     check(bt_scene_set_camera_aspect(scene, camera, (float)args.width / (float)args.height), "aspect");  // :218-223
+    if (args.has_lens) check(bt_scene_set_lens(scene, &args.lens), "bt_scene_set_lens");
 
     bt_config cfg;
     bt_config_default(&cfg);

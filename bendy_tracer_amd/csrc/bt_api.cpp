@@ -76,6 +76,8 @@ struct bt_scene {
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bt_stats last{};
+    bool lens_on = false;          // lens extension (not in the reference), bt_scene_set_lens
+    bt_lens lens{};
     bool stats_pending = false;
 
     ~bt_scene() {
@@ -196,6 +198,12 @@ int fill_launch(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt
     P.world = 1;
     P.sharded = 0;
     P.counters = s->d_counters;
+    P.lens_on = s->lens_on ? 1 : 0;
+    P.lens_c.x = s->lens.centre[0]; P.lens_c.y = s->lens.centre[1]; P.lens_c.z = s->lens.centre[2];
+    P.lens_rs = s->lens.rs;
+    P.lens_step = s->lens.step;
+    P.lens_radius = s->lens.radius;
+    P.lens_max_steps = (int32_t)s->lens.max_steps;
     return 0;
 }
 
@@ -232,7 +240,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     const int variant = g_kernel_variant ? g_kernel_variant : env_variant;
     const bool can_sort = P.max_bounces < 250 && P.max_volume_bounces < 250 &&
                           s->flat.lds_bytes() + bt_sorted_state_bytes(output) <= 64 * 1024;
-    const bool use_sorted = can_sort && variant == BT_KERNEL_SORTED;
+    const bool use_sorted = can_sort && variant == BT_KERNEL_SORTED && !P.lens_on;   // the lens lives in the lanes kernel
     if (use_sorted)
         BT_HIP(bt_launch_render_sorted(&P, output, grid, s->flat.lds_bytes(), stream));
     else
@@ -387,6 +395,20 @@ int bt_scene_set_camera_aspect(bt_scene *scene, uint64_t camera_ref, float aspec
     return 0;
 }
 
+int bt_scene_set_lens(bt_scene *scene, const bt_lens *lens) {
+    if (!scene) return set_error(BT_ERR_INVALID_ARG, "null scene");
+    if (!lens) {
+        scene->lens_on = false;
+        return 0;
+    }
+    if (!(lens->rs >= 0.0f) || !(lens->step > 0.0f) || !(lens->radius > lens->rs) || lens->max_steps == 0 ||
+        lens->max_steps > 0x7fffffffu)
+        return set_error(BT_ERR_INVALID_ARG, "lens needs rs >= 0, step > 0, radius > rs, max_steps > 0");
+    scene->lens = *lens;
+    scene->lens_on = true;
+    return 0;
+}
+
 int bt_scene_object_count(const bt_scene *scene) { return scene ? (int)scene->scene.objects.size() : 0; }
 int bt_scene_data_count(const bt_scene *scene) { return scene ? (int)scene->scene.data.size() : 0; }
 
@@ -489,6 +511,7 @@ int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {
         float ms = 0.0f;
         BT_HIP(hipEventElapsedTime(&ms, scene->ev_start, scene->ev_stop));
         scene->last.segments = c[0];
+        scene->last.lens_steps = c[1];
         scene->last.kernel_ms = ms;
         scene->stats_pending = false;
     }

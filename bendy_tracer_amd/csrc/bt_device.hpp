@@ -327,4 +327,98 @@ BT_DEV unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+// ---- lens EXTENSION (not in the reference: SURVEY F1, 8 f-4; default off; mirrors oracle/bt_oracle.c) ----
+// A point mass of Schwarzschild radius rs bends every non-marching path segment.  Inside the sphere of
+// influence the photon follows the Schwarzschild null geodesic, integrated with fixed-step RK4 on
+// (x, v): x'' = -1.5 rs h^2 x / r^5 with h = |x x v| (conserved); every step's chord is intersected like
+// a volume-march step (clip [0, |chord|]).  Outside the sphere rays are straight.
+BT_DEV V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+BT_DEV V3 lens_accel(const BtLaunch &P, V3 x, float h2) {
+    const V3 rel = x - mk(P.lens_c);
+    const float r2 = len2(rel);
+    const float r = sqrtf(r2);
+    const float r5 = (r2 * r2) * r;
+    const float k = (-1.5f * P.lens_rs * h2) / r5;
+    return rel * k;
+}
+BT_DEV void lens_rk4(const BtLaunch &P, float h2, V3 x, V3 v, V3 &x1, V3 &v1) {
+    const float dt = P.lens_step, hdt = 0.5f * dt, w = dt / 6.0f;
+    const V3 k1x = v, k1v = lens_accel(P, x, h2);
+    const V3 k2x = v + k1v * hdt, k2v = lens_accel(P, x + k1x * hdt, h2);
+    const V3 k3x = v + k2v * hdt, k3v = lens_accel(P, x + k2x * hdt, h2);
+    const V3 k4x = v + k3v * dt, k4v = lens_accel(P, x + k3x * dt, h2);
+    const V3 sx = (k1x + (k2x + k3x) * 2.0f) + k4x;
+    const V3 sv = (k1v + (k2v + k3v) * 2.0f) + k4v;
+    x1 = x + sx * w;
+    v1 = v + sv * w;
+}
+// One bent path segment from (x, v).  Returns 1 hit (h = hit on the chord (x, v), which are updated to that
+// chord), 0 miss ((x, v) = the ray that reaches the root), -1 captured by the horizon.  `travelled` = path
+// length before the returned chord.
+BT_DEV int lens_trace(const BtLaunch &P, V3 &x, V3 &v, HitRec &h, float &travelled, unsigned long long &steps) {
+    const V3 c = mk(P.lens_c);
+    const float R2 = P.lens_radius * P.lens_radius, rs2 = P.lens_rs * P.lens_rs;
+    float remaining = P.clip_max;
+    travelled = 0.0f;
+    bool first = true;
+    int steps_left = P.lens_max_steps;
+    h.prim = -1;
+    for (;;) {
+        V3 rel = x - c;
+        float r2 = len2(rel);
+        if (!(r2 <= R2)) {
+            // straight flight to the sphere of influence (or to the end of the clip)
+            const float hb = dot(rel, v), cc = r2 - R2, disc = hb * hb - cc;
+            float t_enter = __builtin_inff();
+            if (disc >= 0.0f) {
+                const float te = -hb - sqrtf(disc);
+                if (te > 0.0f) t_enter = te;
+            }
+            const float seg = fminf(t_enter, remaining);
+            h = intersect(P, x, v, first ? P.clip_min : 0.0f, seg, -1);
+            if (h.prim >= 0) return 1;
+            if (!(t_enter < remaining)) return 0;
+            x = x + v * t_enter;
+            remaining -= t_enter;
+            travelled += t_enter;
+            first = false;
+        }
+        const float h2 = len2(cross(x - c, v));
+        for (;;) {
+            if (steps_left-- <= 0) {           // step budget exhausted: the segment is abandoned as a miss
+                v = normalize(v);
+                return 0;
+            }
+            steps += 1;
+            V3 x1, v1;
+            lens_rk4(P, h2, x, v, x1, v1);
+            const V3 chord = x1 - x;
+            const float len = sqrtf(len2(chord));
+            const V3 dirn = chord * (1.0f / len);
+            const float seg = fminf(len, remaining);
+            h = intersect(P, x, dirn, first ? P.clip_min : 0.0f, seg, -1);
+            if (h.prim >= 0) {
+                v = dirn;
+                return 1;
+            }
+            if (!(len < remaining)) {
+                v = dirn;
+                return 0;
+            }
+            remaining -= len;
+            travelled += len;
+            first = false;
+            x = x1;
+            v = v1;
+            rel = x - c;
+            r2 = len2(rel);
+            if (r2 <= rs2) return -1;
+            if (r2 > R2 && dot(rel, v) > 0.0f) {
+                v = normalize(v);
+                break;
+            }
+        }
+    }
+}
+
 } // namespace

@@ -41,7 +41,8 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #ifndef BT_WAVES_PER_SIMD
 #define BT_WAVES_PER_SIMD 5
 #endif
-template <int OUTPUT>
+// LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
+template <int OUTPUT, bool LENS>
 __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
 
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
     int bounce = 0, vbounce = 0, last_object = -1;
     uint32_t event = 0, k = 0;
     bool pending = true;               // the lane has no ray yet: its next event is the camera ray
-    unsigned long long segments = 0;
+    unsigned long long segments = 0, lens_steps = 0;
 
     // mod.rs:304-315 -> Chunk::write_* -> Buffer::write_* (buffer.rs:159-178): one sample is done
     auto finish_sample = [&]() {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
         int ev = EV_GEN;
         // manifold of this iteration's hit (shading events only)
         V3 pos = ro, normal = mk(0, 0, 0);
-        float hit_t = 0.0f;
+        float hit_depth = 0.0f;                         // Manifold.t of the hit, for the Depth output
         bool front = false, inside = false, vol_back = false;
         int pobject = -1, mat_index = 0, vol_index = 0;
         V3 prim_c = mk(0, 0, 0);
@@ -141,9 +142,18 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
             segments += 1;
             const float tmin = marching ? 0.0f : P.clip_min;
             const float tmax = marching ? P.volume_step : P.clip_max;
-            const HitRec h = intersect(P, ro, rd, tmin, tmax, last_object);
-            bool ended = false;
-            if (h.prim < 0) {
+            HitRec h;
+            bool ended = false, captured = false;
+            float travelled = 0.0f;
+            if (LENS && !marching) {
+                // bent segment: (ro, rd) become the chord that hits, or the ray that reaches the root
+                captured = lens_trace(P, ro, rd, h, travelled, lens_steps) < 0;
+            } else {
+                h = intersect(P, ro, rd, tmin, tmax, last_object);
+            }
+            if (captured) {
+                ended = true;                         // swallowed by the horizon: the path returns black
+            } else if (h.prim < 0) {
                 // sample_root (mod.rs:429-452)
                 L = L + beta * mk(P.root_color);
                 if (OUTPUT != 0 && !have_first) {
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
                 pobject = pl.kind_object >> 8;
                 prim_c = mk(pl.c);
                 prim_radius = pl.radius;
-                hit_t = h.t;
+                hit_depth = LENS ? h.t + travelled : h.t;
                 pos = ro + rd * h.t;
                 bool vol_face = false;
                 if (h.inside) {                       // generate_volume_manifold (sphere.rs:63-83)
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
                         have_first = true;
                         if (OUTPUT == 1) first = mk(0.8f, 0.8f, 0.8f);
                         if (OUTPUT == 2) first = normal;
-                        if (OUTPUT == 3) first_depth = hit_t;
+                        if (OUTPUT == 3) first_depth = hit_depth;
                     }
                 }                                                         // else pass through: Ray::new(pos, rd)
                 if (vol_back) {                                           // mod.rs:504-505
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
                 if (scatter) {      // data.albedo ColorData (material.rs:99-104,140-145,169-174)
                     if (OUTPUT == 1) first = mk(M.albedo);
                     if (OUTPUT == 2) first = normal;
-                    if (OUTPUT == 3) first_depth = hit_t;
+                    if (OUTPUT == 3) first_depth = hit_depth;
                 } else {            // ColorData::from_emitted(emitted) (mod.rs:483-485)
                     if (OUTPUT == 1) first = mk(M.emitted);
                 }
@@ -401,6 +411,10 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
     if (P.counters) {
         unsigned long long s = wave_sum(segments);
         if (lane == 0 && s) atomicAdd(&P.counters[0], s);
+        if (LENS) {
+            unsigned long long ls = wave_sum(lens_steps);
+            if (lane == 0 && ls) atomicAdd(&P.counters[1], ls);
+        }
     }
 }
 
@@ -485,11 +499,20 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
     // kernel runs 5 waves/SIMD, and a loss when the LDS tables are large (cloud.json), so 256 it is.
     const unsigned block = BT_BLOCK_THREADS;
     dim3 g(grid * (256 / block)), b(block);
+    if (P->lens_on) {
+        switch (output) {
+        case 0: hipLaunchKernelGGL((bt_render_kernel<0, true>), g, b, lds_bytes, stream, *P); break;
+        case 1: hipLaunchKernelGGL((bt_render_kernel<1, true>), g, b, lds_bytes, stream, *P); break;
+        case 2: hipLaunchKernelGGL((bt_render_kernel<2, true>), g, b, lds_bytes, stream, *P); break;
+        default: hipLaunchKernelGGL((bt_render_kernel<3, true>), g, b, lds_bytes, stream, *P); break;
+        }
+        return hipGetLastError();
+    }
     switch (output) {
-    case 0: hipLaunchKernelGGL(bt_render_kernel<0>, g, b, lds_bytes, stream, *P); break;
-    case 1: hipLaunchKernelGGL(bt_render_kernel<1>, g, b, lds_bytes, stream, *P); break;
-    case 2: hipLaunchKernelGGL(bt_render_kernel<2>, g, b, lds_bytes, stream, *P); break;
-    default: hipLaunchKernelGGL(bt_render_kernel<3>, g, b, lds_bytes, stream, *P); break;
+    case 0: hipLaunchKernelGGL((bt_render_kernel<0, false>), g, b, lds_bytes, stream, *P); break;
+    case 1: hipLaunchKernelGGL((bt_render_kernel<1, false>), g, b, lds_bytes, stream, *P); break;
+    case 2: hipLaunchKernelGGL((bt_render_kernel<2, false>), g, b, lds_bytes, stream, *P); break;
+    default: hipLaunchKernelGGL((bt_render_kernel<3, false>), g, b, lds_bytes, stream, *P); break;
     }
     return hipGetLastError();
 }

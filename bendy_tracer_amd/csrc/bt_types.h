@@ -115,5 +115,10 @@ struct BtLaunch {
     uint32_t rank, world;
     int32_t sharded;                  // 0: out = row-major frame; 1: out = this rank's shard
     float *out;
-    unsigned long long *counters;     // [0] segments, [1] samples
+    unsigned long long *counters;     // [0] path segments, [1] lens RK4 steps
+    // lens EXTENSION (not in the reference, default off; include/bendy_hip.h bt_lens)
+    int32_t lens_on;
+    BtV3 lens_c;
+    float lens_rs, lens_step, lens_radius;
+    int32_t lens_max_steps;
 };

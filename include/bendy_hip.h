@@ -80,7 +80,25 @@ typedef struct {
     uint64_t segments;         /* try_hit / try_hit_volume calls (mod.rs:389-427) */
     uint64_t pixels;
     float kernel_ms;           /* HIP-event time of the render kernel(s), 0 if not measured */
+    uint64_t lens_steps;       /* RK4 steps taken by the lens extension (0 when it is off) */
 } bt_stats;
+
+/* EXTENSION -- NOT IN THE REFERENCE.  bendy-tracer v1 traces straight rays only (`Ray::at` is
+ * origin + t * direction, tracer/ray.rs:115-117); "gravitational lensing" exists in its README as an
+ * aspiration.  This optional mode (off unless set) bends every non-marching path segment around one point
+ * mass: inside `radius` the photon follows the Schwarzschild null geodesic, integrated with fixed-step RK4
+ * (x'' = -1.5 rs h^2 x / r^5, h = |x x v|), and each step's chord is intersected like a volume-march step;
+ * outside `radius` rays are straight; r <= rs swallows the path (black).  Light-sampling pdfs
+ * (material.rs:313-316) still assume straight visibility.  There is no reference behaviour to match:
+ * validation is analytic (weak-field deflection 2 rs / b, capture below b = 3 sqrt(3)/2 rs) plus GPU == CPU
+ * oracle; with the lens unset every code path and every pixel is exactly what it is without this extension. */
+typedef struct {
+    float centre[3];
+    float rs;                  /* Schwarzschild radius, scene units */
+    float step;                /* RK4 step (affine length) */
+    float radius;              /* sphere of influence */
+    uint32_t max_steps;        /* RK4 steps per path segment before the segment is abandoned as a miss */
+} bt_lens;
 
 typedef struct bt_scene bt_scene; /* opaque; replaces `Scene` (scene/mod.rs:84-90) */
 
@@ -110,6 +128,8 @@ int bt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_
 int bt_scene_find_by_tag(const bt_scene *scene, const char *tag, uint64_t *object_ref);
 /* object.as_camera_mut().unwrap().aspect_ratio = a (main.rs:218-223, quirk Q12). */
 int bt_scene_set_camera_aspect(bt_scene *scene, uint64_t camera_ref, float aspect_ratio);
+/* Lens extension (see bt_lens): NULL switches it off again. */
+int bt_scene_set_lens(bt_scene *scene, const bt_lens *lens);
 int bt_scene_object_count(const bt_scene *scene);
 int bt_scene_data_count(const bt_scene *scene);
 /* Flattened primitive table as uploaded to the GPU, for loader cross-checks:

@@ -227,6 +227,7 @@ typedef struct { /* ray.rs:35-47 */
     float t;
     ray_t ray;
     int object, mat, vol; /* indices or -1 */
+    float depth_extra;    /* lens extension: path length before the chord that hit; 0 otherwise */
 } manifold_t;
 typedef struct { v3 color, albedo, normal; float depth; } colordata_t; /* ray.rs:49-55 */
 
@@ -347,6 +348,7 @@ static manifold_t sphere_surface_manifold(const bto_object *o, int oi, v3 tr, ra
     m.object = oi;
     m.mat = o->material;
     m.vol = o->volume;
+    m.depth_extra = 0.0f;
     return m;
 }
 /* sphere.rs:121-148.  `discriminant.is_sign_negative()` is restated as !(d >= 0):
@@ -384,6 +386,7 @@ static int sphere_hit_volumetric(const bto_object *o, int oi, v3 tr, const ray_t
         m.object = oi;
         m.mat = o->material;
         m.vol = o->volume;
+        m.depth_extra = 0.0f;
         *out = m;
         return 1;
     }
@@ -439,6 +442,7 @@ static int rect_hit(const bto_rect *r, int oi, const bto_affine *tf, const ray_t
     m.object = oi;
     m.mat = r->material;
     m.vol = -1;
+    m.depth_extra = 0.0f;
     *out = m;
     return 1;
 }
@@ -639,7 +643,7 @@ static int volume_shade(const bto_scene *sc, const bto_data *vol, rng_t *rng, co
         cd_out->color = V3(0.8f, 0.8f, 0.8f);
         cd_out->albedo = V3(0.8f, 0.8f, 0.8f);
         cd_out->normal = m->normal;
-        cd_out->depth = m->t;
+        cd_out->depth = m->t + m->depth_extra;
         return 1;
     }
     *ray_out = ray_new(m->position, m->ray.direction);
@@ -679,7 +683,7 @@ static shader_t material_shade(const bto_scene *sc, const bto_data *d, rng_t *rn
     if (d->kind == BTO_EMISSIVE) return sh; /* :193-197 */
     sh.has_albedo = 1;
     sh.albedo.normal = m->normal;
-    sh.albedo.depth = m->t;
+    sh.albedo.depth = m->t + m->depth_extra;
     if (d->kind == BTO_FLAT) { /* :88-97 */
         sh.albedo.color = V3(0, 0, 0);
         sh.albedo.albedo = V3(0, 0, 0);
@@ -751,11 +755,10 @@ typedef struct {
 static inline clip_t clip_of(const chunk_state_t *cs) { clip_t c = {cs->cfg.clip_min, cs->cfg.clip_max}; return c; } /* :375-380 */
 static inline clip_t clip_volumetric(const chunk_state_t *cs) { clip_t c = {0.0f, cs->cfg.volume_step}; return c; }    /* :382-387 */
 
-/* :389-402 */
-static int try_hit(chunk_state_t *cs, const ray_t *ray, manifold_t *out) {
+/* the object loop of try_hit (:394-399) over a given clip */
+static int scan_objects(chunk_state_t *cs, const ray_t *ray, float cmin, float cmax, manifold_t *out) {
     int found = 0;
-    clip_t clip = clip_of(cs);
-    cs->rng.segments += 1;
+    clip_t clip = {cmin, cmax};
     for (int i = 0; i < cs->scene->n_objects; ++i) {
         manifold_t m;
         if (object_hit(cs->scene, i, ray, &clip, &m)) {
@@ -764,7 +767,120 @@ static int try_hit(chunk_state_t *cs, const ray_t *ray, manifold_t *out) {
             found = 1;
         }
     }
+    if (found) out->depth_extra = 0.0f;
     return found;
+}
+
+/* ---- lens extension (NOT in the reference; see bt_oracle.h) ---- */
+typedef struct { v3 c; float rs, step, radius; int max_steps; } lens_t;
+static inline lens_t lens_of(const bto_config *cfg) {
+    lens_t ln = {V3(cfg->lens_centre[0], cfg->lens_centre[1], cfg->lens_centre[2]), cfg->lens_rs, cfg->lens_step,
+                 cfg->lens_radius, cfg->lens_max_steps};
+    return ln;
+}
+static inline v3 lens_accel(const lens_t *ln, v3 x, float h2) {
+    v3 rel = vsub(x, ln->c);
+    float r2 = vlen2(rel);
+    float r = sqrtf(r2);
+    float r5 = (r2 * r2) * r;
+    float k = (-1.5f * ln->rs * h2) / r5;
+    return vscale(rel, k);
+}
+static inline void lens_rk4(const lens_t *ln, float h2, v3 x, v3 v, v3 *x1, v3 *v1) {
+    float dt = ln->step, hdt = 0.5f * dt, w = dt / 6.0f;
+    v3 k1x = v, k1v = lens_accel(ln, x, h2);
+    v3 k2x = vadd(v, vscale(k1v, hdt)), k2v = lens_accel(ln, vadd(x, vscale(k1x, hdt)), h2);
+    v3 k3x = vadd(v, vscale(k2v, hdt)), k3v = lens_accel(ln, vadd(x, vscale(k2x, hdt)), h2);
+    v3 k4x = vadd(v, vscale(k3v, dt)), k4v = lens_accel(ln, vadd(x, vscale(k3x, dt)), h2);
+    v3 sx = vadd(vadd(k1x, vscale(vadd(k2x, k3x), 2.0f)), k4x);
+    v3 sv = vadd(vadd(k1v, vscale(vadd(k2v, k3v), 2.0f)), k4v);
+    *x1 = vadd(x, vscale(sx, w));
+    *v1 = vadd(v, vscale(sv, w));
+}
+/* One bent path segment.  1 = hit (out->ray is the chord that hit, out->t its local t), 0 = miss (root),
+ * -1 = captured by the horizon.  `cs` may be NULL (free-space integration); last = the final straight ray. */
+static int lens_trace(chunk_state_t *cs, const bto_config *cfg, const ray_t *ray, manifold_t *out, ray_t *last, int *status) {
+    const lens_t ln = lens_of(cfg);
+    const float R2 = ln.radius * ln.radius, rs2 = ln.rs * ln.rs;
+    v3 x = ray->origin, v = ray->direction;
+    float remaining = cfg->clip_max, travelled = 0.0f;
+    int first = 1, steps_left = ln.max_steps;
+    if (status) *status = 0;
+    for (;;) {
+        v3 rel = vsub(x, ln.c);
+        float r2 = vlen2(rel);
+        if (!(r2 <= R2)) {
+            /* straight flight to the sphere of influence (or to the end of the clip) */
+            float hb = vdot(rel, v), cc = r2 - R2, disc = hb * hb - cc;
+            float t_enter = INFINITY;
+            if (disc >= 0.0f) {
+                float te = -hb - sqrtf(disc);
+                if (te > 0.0f) t_enter = te;
+            }
+            float seg = fminf(t_enter, remaining);
+            ray_t sr = {x, v};
+            *last = sr;
+            if (cs && scan_objects(cs, &sr, first ? cfg->clip_min : 0.0f, seg, out)) {
+                out->depth_extra = travelled;
+                return 1;
+            }
+            if (!(t_enter < remaining)) return 0;
+            x = vadd(x, vscale(v, t_enter));
+            remaining -= t_enter;
+            travelled += t_enter;
+            first = 0;
+        }
+        float h2 = vlen2(vcross(vsub(x, ln.c), v));
+        for (;;) {
+            if (steps_left-- <= 0) {               /* step budget exhausted: the segment is abandoned as a miss */
+                ray_t lr = {x, vnormalize(v)};
+                *last = lr;
+                if (status) *status = 2;
+                return 0;
+            }
+            v3 x1, v1;
+            lens_rk4(&ln, h2, x, v, &x1, &v1);
+            v3 chord = vsub(x1, x);
+            float len = sqrtf(vlen2(chord));
+            ray_t sr = {x, vscale(chord, 1.0f / len)};
+            *last = sr;
+            float seg = fminf(len, remaining);
+            if (cs && scan_objects(cs, &sr, first ? cfg->clip_min : 0.0f, seg, out)) {
+                out->depth_extra = travelled;
+                return 1;
+            }
+            if (!(len < remaining)) { if (status) *status = 2; return 0; }
+            remaining -= len;
+            travelled += len;
+            first = 0;
+            x = x1;
+            v = v1;
+            rel = vsub(x, ln.c);
+            r2 = vlen2(rel);
+            if (r2 <= rs2) { if (status) *status = 1; return -1; }
+            if (r2 > R2 && vdot(rel, v) > 0.0f) {
+                v = vnormalize(v);
+                break;
+            }
+        }
+    }
+}
+int bto_lens_trace_free(const bto_config *cfg, const float *o, const float *d, float *pos_out, float *dir_out) {
+    ray_t ray = {V3(o[0], o[1], o[2]), vnormalize(V3(d[0], d[1], d[2]))}, last = ray;
+    manifold_t m;
+    int status = 0;
+    lens_trace(NULL, cfg, &ray, &m, &last, &status);
+    pos_out[0] = last.origin.x; pos_out[1] = last.origin.y; pos_out[2] = last.origin.z;
+    dir_out[0] = last.direction.x; dir_out[1] = last.direction.y; dir_out[2] = last.direction.z;
+    return status;
+}
+
+/* :389-402.  With the lens extension on: 1 hit, 0 miss, -1 captured; `*last` is the ray that reaches the root. */
+static int try_hit(chunk_state_t *cs, const ray_t *ray, manifold_t *out, ray_t *last) {
+    cs->rng.segments += 1;
+    *last = *ray;
+    if (cs->cfg.lens_on) return lens_trace(cs, &cs->cfg, ray, out, last, NULL);
+    return scan_objects(cs, ray, cs->cfg.clip_min, cs->cfg.clip_max, out);
 }
 /* :404-427 */
 static int try_hit_volume(chunk_state_t *cs, const ray_t *ray, int last_object, manifold_t *out) {
@@ -781,6 +897,7 @@ static int try_hit_volume(chunk_state_t *cs, const ray_t *ray, int last_object, 
             found = 1;
         }
     }
+    if (found) out->depth_extra = 0.0f;
     return found;
 }
 
@@ -799,6 +916,7 @@ static colordata_t sample_root(chunk_state_t *cs, const ray_t *ray) {
     m.t = cs->cfg.clip_max;
     m.ray = *ray;
     m.object = m.mat = m.vol = -1;
+    m.depth_extra = 0.0f;
     clip_t clip = clip_of(cs);
     v3 emitted = material_emitted(material);
     shader_t data = material_shade(cs->scene, material, &cs->rng, &m, &clip);
@@ -848,7 +966,10 @@ static colordata_t sample_volume(chunk_state_t *cs, const manifold_t *m, int vol
 static colordata_t sample(chunk_state_t *cs, const ray_t *ray, int bounce) {
     if (bounce > cs->cfg.max_bounces) return colordata_default();
     manifold_t m;
-    if (try_hit(cs, ray, &m)) {
+    ray_t last;
+    int hit = try_hit(cs, ray, &m, &last);
+    if (hit < 0) return colordata_default();      /* lens extension: swallowed by the horizon */
+    if (hit) {
         if (face_is_surface(m.face)) {
             if (m.mat >= 0) return sample_surface(cs, &m, m.mat, bounce);
             return colordata_default();
@@ -856,7 +977,7 @@ static colordata_t sample(chunk_state_t *cs, const ray_t *ray, int bounce) {
         if (m.vol >= 0) return sample_volume(cs, &m, m.vol, bounce, 0);
         return colordata_default();
     }
-    return sample_root(cs, ray);
+    return sample_root(cs, &last);
 }
 /* :344-373 */
 static colordata_t sample_volumetric(chunk_state_t *cs, const ray_t *ray, int last_object, int bounce, int volume_bounce) {
@@ -886,7 +1007,10 @@ static colordata_t sample_iterative(chunk_state_t *cs, const ray_t *ray0) {
         int hit;
         if (!marching) {
             if (bounce > cs->cfg.max_bounces) break;
-            hit = try_hit(cs, &ray, &m);
+            ray_t last;
+            hit = try_hit(cs, &ray, &m, &last);
+            if (hit < 0) break;                   /* lens extension: swallowed by the horizon */
+            ray = last;
             volume_bounce = 0;
         } else {
             if (volume_bounce > cs->cfg.max_volume_bounces) break;

@@ -95,7 +95,21 @@ typedef struct {
     uint32_t sample_base;      /* index of this call's first sample (progressive calls) */
     int32_t recursive;         /* 1 = recursive evaluation exactly as the reference nests it;
                                   0 = iterative throughput form */
+    /* EXTENSION, NOT IN THE REFERENCE ("parity unpinned", default off): a point mass
+     * bends every non-marching path segment.  Inside the sphere of influence the photon is stepped with
+     * fixed-step RK4 along the Schwarzschild null geodesic (x'' = -1.5 rs h^2 x / r^5, h = |x x v|); each
+     * step's chord is intersected like a volume-march step.  Outside the sphere rays are straight. */
+    int32_t lens_on;
+    float lens_centre[3];
+    float lens_rs;             /* Schwarzschild radius, scene units */
+    float lens_step;           /* RK4 step (affine length) */
+    float lens_radius;         /* sphere of influence */
+    int32_t lens_max_steps;    /* RK4 steps per path segment before the segment is abandoned (treated as a miss) */
 } bto_config;
+
+/* Lens extension, free space: integrates one ray and reports where it ends.  Returns 0 escaped (out = final
+ * position, direction), 1 captured by the horizon, 2 step / length budget exhausted. */
+int bto_lens_trace_free(const bto_config *cfg, const float *origin3, const float *dir3, float *pos_out3, float *dir_out3);
 
 /* Render `samples * n^2` rays per pixel and ADD them into rgba (row-major,
  * 4 floats per pixel, alpha untouched): Tracer::render, tracer/mod.rs:179-202.

@@ -66,18 +66,35 @@ class Config(C.Structure):
     _fields_ = [("max_bounces", C.c_int32), ("max_volume_bounces", C.c_int32), ("clip_min", C.c_float),
                 ("clip_max", C.c_float), ("volume_step", C.c_float), ("chunks_x", C.c_int32),
                 ("chunks_y", C.c_int32), ("output", C.c_int32), ("samples", C.c_int32),
-                ("subsample_n", C.c_int32), ("sample_base", C.c_uint32), ("recursive", C.c_int32)]
+                ("subsample_n", C.c_int32), ("sample_base", C.c_uint32), ("recursive", C.c_int32),
+                # lens extension (NOT in the reference; default off)
+                ("lens_on", C.c_int32), ("lens_centre", C.c_float * 3), ("lens_rs", C.c_float),
+                ("lens_step", C.c_float), ("lens_radius", C.c_float), ("lens_max_steps", C.c_int32)]
 
 
 def default_config(samples=1, subsample_n=0, output=OUT_FULL, recursive=1, chunks=(8, 4), sample_base=0,
-                   max_bounces=8, max_volume_bounces=None, volume_step=0.1):
+                   max_bounces=8, max_volume_bounces=None, volume_step=0.1, lens=None):
     """Config::DEFAULT (mod.rs:29-38) with main.rs's 8x4 chunks (main.rs:225-230).
     Q1 (mod.rs:224): a RenderConfig.max_bounces override also overrides max_volume_bounces;
-    without an override max_volume_bounces stays 32."""
-    return Config(max_bounces=max_bounces, max_volume_bounces=32 if max_volume_bounces is None else max_volume_bounces,
-                  clip_min=0.01, clip_max=1000.0, volume_step=volume_step, chunks_x=chunks[0], chunks_y=chunks[1],
-                  output=output, samples=samples, subsample_n=subsample_n, sample_base=sample_base,
-                  recursive=recursive)
+    without an override max_volume_bounces stays 32.
+    lens = dict(centre=(x, y, z), rs=, step=, radius=, max_steps=) switches the lens extension on."""
+    cfg = Config(max_bounces=max_bounces, max_volume_bounces=32 if max_volume_bounces is None else max_volume_bounces,
+                 clip_min=0.01, clip_max=1000.0, volume_step=volume_step, chunks_x=chunks[0], chunks_y=chunks[1],
+                 output=output, samples=samples, subsample_n=subsample_n, sample_base=sample_base,
+                 recursive=recursive)
+    if lens is not None:
+        cfg.lens_on = 1
+        cfg.lens_centre[0], cfg.lens_centre[1], cfg.lens_centre[2] = lens["centre"]
+        cfg.lens_rs, cfg.lens_step, cfg.lens_radius = lens["rs"], lens["step"], lens["radius"]
+        cfg.lens_max_steps = lens.get("max_steps", 4096)
+    return cfg
+
+
+def lens_trace_free(cfg, origin, direction):
+    """Lens extension in empty space: (status, end position, end direction); status 0 escaped, 1 captured, 2 budget."""
+    pos, d = (C.c_float * 3)(), (C.c_float * 3)()
+    st = lib().bto_lens_trace_free(C.byref(cfg), _f3(origin), _f3(direction), pos, d)
+    return st, np.array(pos[:], np.float32), np.array(d[:], np.float32)
 
 
 def build(force=False):
@@ -122,6 +139,8 @@ def lib():
         L.bto_preview.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(C.c_uint8)]
         L.bto_chunk_bounds.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                        C.POINTER(C.c_uint32)]
+        L.bto_lens_trace_free.restype = C.c_int
+        L.bto_lens_trace_free.argtypes = [C.POINTER(Config), fp, fp, fp, fp]
         _lib = L
     return _lib
 
