@@ -83,6 +83,28 @@ def load_pmc_traffic(workload):
         return None
 
 
+def lens_extension_rate(b, torch, scene_name, w, h, spp=16, steps=3):
+    """Throughput of the same frame with the gravitational-lens EXTENSION switched on.  Not part of `value`:
+    the reference has no lens code, so this mode has no reference behaviour and no parity claim
+    beyond GPU == this repo's CPU oracle; BASELINE.json's config text mentions geodesic stepping, hence the number."""
+    lens = dict(centre=(0.6, 0.4, 4.0), rs=0.15, step=0.1, radius=6.0, max_steps=800)
+    sc = b.Scene.load(os.path.join(ROOT, "scenes", f"{scene_name}.json.gz"))
+    cam = sc.find_by_tag("camera")
+    sc.set_camera_aspect(cam, w / h)
+    sc.set_lens(**lens)
+    buf = b.Buffer.new(w, h)
+    tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
+    ms = []
+    for i in range(steps + 1):
+        tr.render(sc, cam, b.RenderConfig.with_samples(spp), buf, seed=SEED, sample_base=i * spp)
+        st = sc.last_stats()
+        ms.append(st.kernel_ms)
+    k = statistics.mean(ms[1:])
+    return {"value": round(w * h * spp / k / 1e3, 1), "unit": "Msamples/s", "kernel_ms": round(k, 3), "spp_per_step": spp,
+            "rk4_steps_per_sample": round(st.lens_steps / st.samples, 1), "lens": lens,
+            "note": "extension, not in the reference; fixed-step RK4 on the Schwarzschild null geodesic"}
+
+
 class ShardExchange:
     """Rank-local shard of running sums + the frame exchange of the N > 1 path."""
 
@@ -266,6 +288,8 @@ def main():
         }
         if verified is not None:
             out["verified_vs_single_rank"] = verified
+        if world == 1 and args.workload == "C3":
+            out["lens_extension"] = lens_extension_rate(b, torch, scene_name, w, h)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_name, w, h, args.cpu_budget)
         print(json.dumps(out), flush=True)
