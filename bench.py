@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-overlap", action="store_true", help="run the frame exchange on the render stream")
     ap.add_argument("--verify", action="store_true", help="compare the gathered frame with a one-rank render of the same steps")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (process group, shard, all-gather, un-permute) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -183,8 +185,12 @@ def main():
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_path = world > 1 or args.force_dist          # `dist_path` replaces `world > 1` below
+    if dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -197,24 +203,24 @@ def main():
     scene.set_camera_aspect(cam, w / h)                     # main.rs:218-223
     tracer = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
     rc = b.RenderConfig.with_samples(spp)
-    if world == 1:
+    if not dist_path:
         frame = b.Buffer.new(w, h)
     else:
         ex = ShardExchange(b, torch, dist, w, h, rank, world, args.backend, overlap=not args.no_overlap)
         frame = ex.frame
 
     def step(i):
-        if world == 1:
+        if not dist_path:
             tracer.render(scene, cam, rc, frame, seed=SEED, sample_base=i * spp)
         else:
             tracer.render_shard(scene, cam, rc, ex.shard, w, h, rank, world, seed=SEED, sample_base=i * spp)
             ex.exchange(i)
 
     def sync():
-        if world > 1:
+        if dist_path:
             ex.drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_path:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -229,7 +235,7 @@ def main():
         ev[i][1].record()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_path:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -248,7 +254,7 @@ def main():
     # segment counts and the library's own HIP-event kernel times: replay the same renders, untimed
     kernel_ms, segments = [], []
     for i in range(args.steps):
-        if world == 1:
+        if not dist_path:
             tracer.render(scene, cam, rc, frame, seed=SEED, sample_base=(args.warmup + i) * spp)
         else:
             tracer.render_shard(scene, cam, rc, ex.shard, w, h, rank, world, seed=SEED, sample_base=(args.warmup + i) * spp)
@@ -268,7 +274,7 @@ def main():
                                f"(max_bounces 8, max_volume_bounces 32, clip 0.01..1000, volume_step 0.1, Output::Full), "
                                f"flat space (the reference has no lens code), seed 0x5EED",
                    "samples_per_step": w * h * spp,
-                   "parallelism": (f"tiles{world}" + ("" if args.no_overlap else "+overlapped-allgather")) if world > 1 else "single"},
+                   "parallelism": (f"tiles{world}" + ("" if args.no_overlap else "+overlapped-allgather")) if dist_path else "single"},
     }
     if rank == 0:
         k_ms = statistics.mean(kernel_ms)
@@ -293,7 +299,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_name, w, h, args.cpu_budget)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_path:
         dist.barrier()
         dist.destroy_process_group()
 
