@@ -144,6 +144,14 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -c 'import __graft_entry__ "
             "as g; g.build()'` or `make -C bendy_tracer_amd/csrc`).  There is no CPU fallback.")
+    # PyTorch bundles its own HIP / HSA runtime.  Two copies of the runtime in one process cannot both own
+    # the GPU (the second one reports "no ROCm-capable device"), so when torch is installed it is imported
+    # FIRST and libbendy_hip.so then binds to the runtime torch has already loaded.  Standalone C/C++ users
+    # (the CLI) use /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, fp = C.c_void_p, C.POINTER(C.c_float)
     L.bt_last_error.restype = C.c_char_p

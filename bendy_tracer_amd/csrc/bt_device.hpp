@@ -352,69 +352,86 @@ BT_DEV void lens_rk4(const BtLaunch &P, float h2, V3 x, V3 v, V3 &x1, V3 &v1) {
     x1 = x + sx * w;
     v1 = v + sv * w;
 }
-// One bent path segment from (x, v).  Returns 1 hit (h = hit on the chord (x, v), which are updated to that
-// chord), 0 miss ((x, v) = the ray that reaches the root), -1 captured by the horizon.  `travelled` = path
-// length before the returned chord.
-BT_DEV int lens_trace(const BtLaunch &P, V3 &x, V3 &v, HitRec &h, float &travelled, unsigned long long &steps) {
+// State of a bent path segment that is marched in instalments (so that a wave is not held back by its
+// longest segment): the photon itself lives in the caller's (x, v).
+struct LensState {
+    float remaining, travelled, h2;
+    int steps_left;
+    bool first, inside;        // inside: h2 is valid and the RK4 march is in progress
+};
+BT_DEV void lens_begin(const BtLaunch &P, LensState &st) {
+    st.remaining = P.clip_max;
+    st.travelled = 0.0f;
+    st.h2 = 0.0f;
+    st.steps_left = P.lens_max_steps;
+    st.first = true;
+    st.inside = false;
+}
+// Advances the bent segment from (x, v) by at most `budget` RK4 steps.  Returns 2 = not finished (call
+// again), 1 = hit (h = hit on the chord (x, v), which are updated to that chord), 0 = miss ((x, v) = the ray
+// that reaches the root), -1 = captured by the horizon.  st.travelled = path length before the returned
+// chord.  The arithmetic and its order are those of lens_trace() in oracle/bt_oracle.c.
+BT_DEV int lens_advance(const BtLaunch &P, V3 &x, V3 &v, LensState &st, HitRec &h, int budget, unsigned long long &steps) {
     const V3 c = mk(P.lens_c);
     const float R2 = P.lens_radius * P.lens_radius, rs2 = P.lens_rs * P.lens_rs;
-    float remaining = P.clip_max;
-    travelled = 0.0f;
-    bool first = true;
-    int steps_left = P.lens_max_steps;
     h.prim = -1;
     for (;;) {
-        V3 rel = x - c;
-        float r2 = len2(rel);
-        if (!(r2 <= R2)) {
-            // straight flight to the sphere of influence (or to the end of the clip)
-            const float hb = dot(rel, v), cc = r2 - R2, disc = hb * hb - cc;
-            float t_enter = __builtin_inff();
-            if (disc >= 0.0f) {
-                const float te = -hb - sqrtf(disc);
-                if (te > 0.0f) t_enter = te;
+        if (!st.inside) {
+            const V3 rel = x - c;
+            const float r2 = len2(rel);
+            if (!(r2 <= R2)) {
+                // straight flight to the sphere of influence (or to the end of the clip)
+                const float hb = dot(rel, v), cc = r2 - R2, disc = hb * hb - cc;
+                float t_enter = __builtin_inff();
+                if (disc >= 0.0f) {
+                    const float te = -hb - sqrtf(disc);
+                    if (te > 0.0f) t_enter = te;
+                }
+                const float seg = fminf(t_enter, st.remaining);
+                h = intersect(P, x, v, st.first ? P.clip_min : 0.0f, seg, -1);
+                if (h.prim >= 0) return 1;
+                if (!(t_enter < st.remaining)) return 0;
+                x = x + v * t_enter;
+                st.remaining -= t_enter;
+                st.travelled += t_enter;
+                st.first = false;
             }
-            const float seg = fminf(t_enter, remaining);
-            h = intersect(P, x, v, first ? P.clip_min : 0.0f, seg, -1);
-            if (h.prim >= 0) return 1;
-            if (!(t_enter < remaining)) return 0;
-            x = x + v * t_enter;
-            remaining -= t_enter;
-            travelled += t_enter;
-            first = false;
+            st.h2 = len2(cross(x - c, v));
+            st.inside = true;
         }
-        const float h2 = len2(cross(x - c, v));
         for (;;) {
-            if (steps_left-- <= 0) {           // step budget exhausted: the segment is abandoned as a miss
+            if (budget-- <= 0) return 2;
+            if (st.steps_left-- <= 0) {        // step budget exhausted: the segment is abandoned as a miss
                 v = normalize(v);
                 return 0;
             }
             steps += 1;
             V3 x1, v1;
-            lens_rk4(P, h2, x, v, x1, v1);
+            lens_rk4(P, st.h2, x, v, x1, v1);
             const V3 chord = x1 - x;
             const float len = sqrtf(len2(chord));
             const V3 dirn = chord * (1.0f / len);
-            const float seg = fminf(len, remaining);
-            h = intersect(P, x, dirn, first ? P.clip_min : 0.0f, seg, -1);
+            const float seg = fminf(len, st.remaining);
+            h = intersect(P, x, dirn, st.first ? P.clip_min : 0.0f, seg, -1);
             if (h.prim >= 0) {
                 v = dirn;
                 return 1;
             }
-            if (!(len < remaining)) {
+            if (!(len < st.remaining)) {
                 v = dirn;
                 return 0;
             }
-            remaining -= len;
-            travelled += len;
-            first = false;
+            st.remaining -= len;
+            st.travelled += len;
+            st.first = false;
             x = x1;
             v = v1;
-            rel = x - c;
-            r2 = len2(rel);
+            const V3 rel = x - c;
+            const float r2 = len2(rel);
             if (r2 <= rs2) return -1;
             if (r2 > R2 && dot(rel, v) > 0.0f) {
                 v = normalize(v);
+                st.inside = false;
                 break;
             }
         }

@@ -42,6 +42,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #define BT_WAVES_PER_SIMD 5
 #endif
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
+#ifndef BT_LENS_BATCH
+#define BT_LENS_BATCH 8            // RK4 steps a lane marches per loop iteration before it yields
+#endif
 template <int OUTPUT, bool LENS>
 __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -110,6 +113,9 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
     uint32_t event = 0, k = 0;
     bool pending = true;               // the lane has no ray yet: its next event is the camera ray
     unsigned long long segments = 0, lens_steps = 0;
+    LensState lens;                    // lens extension: the bent segment in progress (LENS builds only)
+    bool bent = false;
+    lens_begin(P, lens);
 
     // mod.rs:304-315 -> Chunk::write_* -> Buffer::write_* (buffer.rs:159-178): one sample is done
     auto finish_sample = [&]() {
@@ -139,16 +145,26 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
             // ---- TRACE: try_hit (mod.rs:389-402) / try_hit_volume (mod.rs:404-427) ----
             const bool marching = last_object >= 0;
             if (!marching) vbounce = 0;                               // sample() -> sample_volume(.., 0), mod.rs:335
-            segments += 1;
             const float tmin = marching ? 0.0f : P.clip_min;
             const float tmax = marching ? P.volume_step : P.clip_max;
             HitRec h;
             bool ended = false, captured = false;
             float travelled = 0.0f;
             if (LENS && !marching) {
-                // bent segment: (ro, rd) become the chord that hits, or the ray that reaches the root
-                captured = lens_trace(P, ro, rd, h, travelled, lens_steps) < 0;
+                // bent segment, marched BT_LENS_BATCH RK4 steps per iteration: (ro, rd) is the photon; at the
+                // end they are the chord that hits, or the ray that reaches the root
+                if (!bent) {
+                    lens_begin(P, lens);
+                    bent = true;
+                    segments += 1;
+                }
+                const int r = lens_advance(P, ro, rd, lens, h, BT_LENS_BATCH, lens_steps);
+                if (r == 2) continue;                     // still on its way: no event for this lane yet
+                bent = false;
+                captured = r < 0;
+                travelled = lens.travelled;
             } else {
+                segments += 1;
                 h = intersect(P, ro, rd, tmin, tmax, last_object);
             }
             if (captured) {
