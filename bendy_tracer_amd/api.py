@@ -122,7 +122,7 @@ class _CRenderConfig(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("pixels", C.c_uint64), ("kernel_ms", C.c_float),
-                ("lens_steps", C.c_uint64)]
+                ("lens_steps", C.c_uint64), ("slices", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class _CLens(C.Structure):

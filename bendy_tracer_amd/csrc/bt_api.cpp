@@ -3,7 +3,9 @@
 // There is no CPU fallback: without a HIP device every render entry point returns BT_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -74,6 +76,8 @@ struct bt_scene {
     DeviceArray<BtLightFace> d_light_faces;
     DeviceArray<float> d_density;
     unsigned long long *d_counters = nullptr;
+    float *d_scratch = nullptr;    // parked sample values of sliced renders
+    size_t scratch_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bt_stats last{};
     bool lens_on = false;          // lens extension (not in the reference), bt_scene_set_lens
@@ -82,6 +86,7 @@ struct bt_scene {
 
     ~bt_scene() {
         if (d_counters) (void)hipFree(d_counters);
+        if (d_scratch) (void)hipFree(d_scratch);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
     }
@@ -226,6 +231,33 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     const uint32_t grid = sharded ? (n_tiles + world - 1) / world : n_tiles;
 
+    // Few pixels but many samples per pixel (a rank's shard under weak scaling: 1/8 of the tiles at 8x the spp)
+    // means few, very long waves -- one round of the GPU, whose length is that of the heaviest wave (measured:
+    // 18.6 ms instead of 6.2 ms for the same samples, profiles/r01d/shard_slicing.log).  Slice the samples so the
+    // launch has the shape of a full frame; below ~32 samples per lane slicing does not pay (C2).
+    P.slices = 1;
+    P.n_local_px = grid * BT_TILE_DIM * BT_TILE_DIM;
+    P.scratch = nullptr;
+    {
+        const uint64_t total_px = (uint64_t)P.samples * (uint64_t)(P.subsample_n * P.subsample_n);
+        const uint64_t waves = (uint64_t)grid * 4, want = 6 * 256 * 20;          // ~6 rounds of resident waves
+        uint64_t slices = waves >= want ? 1 : (want + waves - 1) / waves;
+        slices = std::min<uint64_t>({slices, total_px / 32, 32});
+        if (const char *e = getenv("BT_SLICES")) slices = std::min<uint64_t>(std::max(1, atoi(e)), std::max<uint64_t>(total_px, 1));   // A/B knob
+        const uint64_t need = (uint64_t)P.n_local_px * total_px * 4 * sizeof(float);
+        if (slices > 1 && need <= (4ull << 30)) {
+            if (s->scratch_bytes < need) {
+                if (s->d_scratch) (void)hipFree(s->d_scratch);
+                s->d_scratch = nullptr;
+                s->scratch_bytes = 0;
+                BT_HIP(hipMalloc((void **)&s->d_scratch, need));
+                s->scratch_bytes = need;
+            }
+            P.slices = (int32_t)slices;
+            P.scratch = s->d_scratch;
+        }
+    }
+
     BT_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), stream));
     BT_HIP(hipEventRecord(s->ev_start, stream));
     // Two bit-identical kernels: the regrouping one (bt_kernels_sorted.hip, path state in LDS, lanes
@@ -241,6 +273,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     const bool can_sort = P.max_bounces < 250 && P.max_volume_bounces < 250 &&
                           s->flat.lds_bytes() + bt_sorted_state_bytes(output) <= 64 * 1024;
     const bool use_sorted = can_sort && variant == BT_KERNEL_SORTED && !P.lens_on;   // the lens lives in the lanes kernel
+    if (use_sorted) P.slices = 1;                 // the regrouping kernel owns whole pixels
     if (use_sorted)
         BT_HIP(bt_launch_render_sorted(&P, output, grid, s->flat.lds_bytes(), stream));
     else
@@ -259,6 +292,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     s->last.samples = pixels * (uint64_t)P.samples * (uint64_t)(P.subsample_n * P.subsample_n);
     s->last.segments = 0;
     s->last.kernel_ms = 0.0f;
+    s->last.slices = (uint32_t)P.slices;
     s->stats_pending = true;
     return BT_IN_PROGRESS;                                             // mod.rs:201
 }

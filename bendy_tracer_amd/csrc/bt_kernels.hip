@@ -84,7 +84,11 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
 
     // ---- tile / pixel mapping ----
     // a workgroup is 1, 2 or 4 waves; four consecutive waves (in launch order) share a 16x16 tile
-    const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // P.slices > 1: `slices` consecutive waves share an 8x8 pixel block, each walks a contiguous range of the
+    // pixels' samples and parks the values in P.scratch (see BtLaunch); the `+=` happens in bt_accumulate_kernel.
+    const uint32_t gwave_raw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t slices = (uint32_t)P.slices;
+    const uint32_t gwave = gwave_raw / slices, slice = gwave_raw % slices;
     const uint32_t slot = gwave >> 2;                 // tile slot in launch order
     const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
     const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
@@ -97,12 +101,15 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
 
     const uint32_t pixel_index = py * P.width + px;
     const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
-    const uint32_t total = in_frame ? (uint32_t)P.samples * nn : 0u;
+    const uint32_t total_px = in_frame ? (uint32_t)P.samples * nn : 0u;          // samples of this pixel
+    const uint32_t k_begin = (uint32_t)(((unsigned long long)total_px * slice) / slices);
+    const uint32_t total = (uint32_t)(((unsigned long long)total_px * (slice + 1)) / slices);   // this lane's end
+    const uint32_t local_px = slot * (BT_TILE_DIM * BT_TILE_DIM) + (wave << 6) + lane;
     const uint32_t sample0 = P.sample_base * nn;
     const V3 mcx = mk(P.cam_cx), mcy = mk(P.cam_cy), mcz = mk(P.cam_cz);
 
     V3 acc = mk(0.0f, 0.0f, 0.0f);
-    if (in_frame) acc = mk(out_px[0], out_px[1], out_px[2]);   // `*r += pixel.r` (buffer.rs:159-164)
+    if (in_frame && slices == 1) acc = mk(out_px[0], out_px[1], out_px[2]);   // `*r += pixel.r` (buffer.rs:159-164)
 
     // per-lane path state
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, -1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
     float first_depth = __builtin_inff();
     bool have_first = false;
     int bounce = 0, vbounce = 0, last_object = -1;
-    uint32_t event = 0, k = 0;
+    uint32_t event = 0, k = k_begin;
     bool pending = true;               // the lane has no ray yet: its next event is the camera ray
     unsigned long long segments = 0, lens_steps = 0;
     LensState lens;                    // lens extension: the bent segment in progress (LENS builds only)
@@ -119,14 +126,20 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
 
     // mod.rs:304-315 -> Chunk::write_* -> Buffer::write_* (buffer.rs:159-178): one sample is done
     auto finish_sample = [&]() {
+        V3 value;
         if (OUTPUT == 0) {
-            acc = acc + L;
+            value = L;
         } else if (OUTPUT == 3) {
             float depth = (first_depth - P.clip_min) / (P.clip_max - P.clip_min);
             depth = fminf(fmaxf(depth, 0.0f), 1.0f);
-            acc = acc + mk(depth, depth, depth);
+            value = mk(depth, depth, depth);
         } else {
-            acc = acc + first;
+            value = first;
+        }
+        if (slices == 1) {
+            acc = acc + value;
+        } else {
+            *(float4 *)(P.scratch + ((size_t)k * P.n_local_px + local_px) * 4) = make_float4(value.x, value.y, value.z, 0.0f);
         }
         k += 1;
     };
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
         }
     }
 
-    if (in_frame) {
+    if (in_frame && slices == 1) {
         out_px[0] = acc.x;
         out_px[1] = acc.y;
         out_px[2] = acc.z;
@@ -432,6 +445,31 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
             if (lane == 0 && ls) atomicAdd(&P.counters[1], ls);
         }
     }
+}
+
+// Second pass of a sliced render: `*r += pixel.r` for every parked sample value, in sample order
+// (buffer.rs:159-164) -- the same additions, in the same order, as the unsliced kernel performs in registers.
+// scratch is sample-major, so a wave reads 1 KB contiguous per sample.
+__global__ __launch_bounds__(256) void bt_accumulate_kernel(BtLaunch P) {
+    const uint32_t slot = blockIdx.x;
+    const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
+    const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
+    const uint32_t px = tx * BT_TILE_DIM + lx, py = ty * BT_TILE_DIM + ly;
+    if (!((ty < P.tiles_y) && (px < P.width) && (py < P.height))) return;
+    float *out_px = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + ly * BT_TILE_DIM + lx) * 4
+                              : P.out + ((size_t)py * P.width + px) * 4;
+    const uint32_t total_px = (uint32_t)P.samples * (uint32_t)(P.subsample_n * P.subsample_n);
+    const float4 *s = (const float4 *)P.scratch + (slot * (BT_TILE_DIM * BT_TILE_DIM) + threadIdx.x);
+    V3 acc = mk(out_px[0], out_px[1], out_px[2]);
+    for (uint32_t k = 0; k < total_px; ++k) {
+        const float4 v = s[(size_t)k * P.n_local_px];
+        acc = acc + mk(v.x, v.y, v.z);
+    }
+    out_px[0] = acc.x;
+    out_px[1] = acc.y;
+    out_px[2] = acc.z;
 }
 
 // shard (tile-major, `world` ranks back to back) -> row-major frame; rgb AND alpha copied.
@@ -514,7 +552,7 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
     // 256).  Measured on MI355X (profiles/r01b/ab_block.log): no gain from smaller workgroups once the
     // kernel runs 5 waves/SIMD, and a loss when the LDS tables are large (cloud.json), so 256 it is.
     const unsigned block = BT_BLOCK_THREADS;
-    dim3 g(grid * (256 / block)), b(block);
+    dim3 g(grid * (256 / block) * (unsigned)P->slices), b(block);    // `slices` waves per 8x8 pixel block
     if (P->lens_on) {
         switch (output) {
         case 0: hipLaunchKernelGGL((bt_render_kernel<0, true>), g, b, lds_bytes, stream, *P); break;
@@ -522,15 +560,20 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
         case 2: hipLaunchKernelGGL((bt_render_kernel<2, true>), g, b, lds_bytes, stream, *P); break;
         default: hipLaunchKernelGGL((bt_render_kernel<3, true>), g, b, lds_bytes, stream, *P); break;
         }
-        return hipGetLastError();
+    } else {
+        switch (output) {
+        case 0: hipLaunchKernelGGL((bt_render_kernel<0, false>), g, b, lds_bytes, stream, *P); break;
+        case 1: hipLaunchKernelGGL((bt_render_kernel<1, false>), g, b, lds_bytes, stream, *P); break;
+        case 2: hipLaunchKernelGGL((bt_render_kernel<2, false>), g, b, lds_bytes, stream, *P); break;
+        default: hipLaunchKernelGGL((bt_render_kernel<3, false>), g, b, lds_bytes, stream, *P); break;
+        }
     }
-    switch (output) {
-    case 0: hipLaunchKernelGGL((bt_render_kernel<0, false>), g, b, lds_bytes, stream, *P); break;
-    case 1: hipLaunchKernelGGL((bt_render_kernel<1, false>), g, b, lds_bytes, stream, *P); break;
-    case 2: hipLaunchKernelGGL((bt_render_kernel<2, false>), g, b, lds_bytes, stream, *P); break;
-    default: hipLaunchKernelGGL((bt_render_kernel<3, false>), g, b, lds_bytes, stream, *P); break;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && P->slices > 1) {
+        hipLaunchKernelGGL(bt_accumulate_kernel, dim3(grid), dim3(256), 0, stream, *P);
+        e = hipGetLastError();
     }
-    return hipGetLastError();
+    return e;
 }
 extern "C" hipError_t bt_launch_unshard(const float *gathered, float *frame, uint32_t width, uint32_t height,
                                         uint32_t tiles_x, uint32_t tiles_y, uint32_t world, uint32_t tiles_per_rank,

@@ -116,6 +116,13 @@ struct BtLaunch {
     int32_t sharded;                  // 0: out = row-major frame; 1: out = this rank's shard
     float *out;
     unsigned long long *counters;     // [0] path segments, [1] lens RK4 steps
+    // Sample slicing (bt_api.cpp decides): when a launch has too few pixels to fill the GPU but many samples per
+    // pixel (a rank's shard under multi-GPU weak scaling), `slices` waves share each 8x8 pixel block, every
+    // sample's value is parked in scratch[sample][local pixel] (4 floats) and bt_accumulate_kernel performs the
+    // per-pixel `+=` in sample order afterwards -- same additions, same order, same bits.
+    int32_t slices;                   // >= 1
+    uint32_t n_local_px;              // grid * 256
+    float *scratch;
     // lens EXTENSION (not in the reference, default off; include/bendy_hip.h bt_lens)
     int32_t lens_on;
     BtV3 lens_c;

@@ -81,6 +81,8 @@ typedef struct {
     uint64_t pixels;
     float kernel_ms;           /* HIP-event time of the render kernel(s), 0 if not measured */
     uint64_t lens_steps;       /* RK4 steps taken by the lens extension (0 when it is off) */
+    uint32_t slices;           /* waves that shared a pixel's samples in the last launch (1 = lane owns all of them) */
+    uint32_t reserved;
 } bt_stats;
 
 /* EXTENSION -- NOT IN THE REFERENCE.  bendy-tracer v1 traces straight rays only (`Ray::at` is

@@ -224,6 +224,50 @@ def test_sharded_render_matches_full_frame(bendy, world):
     assert np.array_equal(unshard_numpy(gathered.cpu().numpy(), w, h, world), full.numpy())
 
 
+# ---- sample slicing: few pixels x many samples per pixel (a rank's shard under weak scaling) ---------------------
+@pytest.mark.parametrize("name,w,h,spp,n,output", [
+    ("scene", 64, 48, 128, 0, 0),        # 12 tiles -> 4 slices of 32 samples
+    ("volume", 48, 32, 96, 0, 0),
+    ("cornell2", 40, 24, 17, 2, 0),      # 68 rays per pixel, ragged frame, slice bounds not a multiple of n^2
+    ("scene", 64, 48, 64, 0, 3),         # AOV through the parked-sample pass
+    ("cloud", 32, 32, 1000, 0, 0),       # 31 slices, the cap
+])
+def test_sliced_render_matches_oracle(bendy, oracle, name, w, h, spp, n, output):
+    """bt_api.cpp slices the samples of a pixel over several waves when the launch has too few pixels to
+    fill the GPU, parks every sample's value and sums them in sample order afterwards: same bits."""
+    buf, stats, _ = gpu_render(bendy, name, w, h, spp, n=n, output=output)
+    assert stats.slices > 1
+    it, seg = oracle_render(oracle, name, w, h, spp, n=n, output=output, recursive=0)
+    assert stats.segments == seg
+    assert np.array_equal(buf.numpy(), it)
+
+
+def test_sliced_render_adds_to_prefilled_buffer(bendy, oracle):
+    w, h = 48, 32
+    sc, cam = gpu_scene(bendy, "scene", w, h)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    buf = bendy.Buffer.new(w, h)
+    tr.render(sc, cam, bendy.RenderConfig.with_samples(8), buf)               # unsliced
+    tr.render(sc, cam, bendy.RenderConfig.with_samples(120), buf)             # sliced, sample_base 8
+    assert sc.last_stats().slices > 1 and buf.samples == 128
+    it, _ = oracle_render(oracle, "scene", w, h, 128)
+    assert np.array_equal(buf.numpy(), it)
+
+
+def test_sliced_shard_matches_full_frame(bendy):
+    import torch
+    w, h, spp, world = 200, 120, 96, 3
+    full, st, _ = gpu_render(bendy, "scene", w, h, spp)
+    sc, cam = gpu_scene(bendy, "scene", w, h)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    shards = [_render_shard(bendy, tr, sc, cam, w, h, spp, r, world) for r in range(world)]
+    assert sc.last_stats().slices > 1
+    out = bendy.Buffer.new(w, h)
+    bendy.unshard(torch.cat(shards), out, world)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.numpy(), full.numpy())
+
+
 # ---- full BASELINE sizes: size-independent properties + oracle spot checks ---------------------------------
 def _spot_check(bendy, oracle, name, w, h, spp, n_pixels, seed=0x5EED):
     buf, stats, _ = gpu_render(bendy, name, w, h, spp, seed=seed)

@@ -1,0 +1,26 @@
+"""Per-rank kernel time under bench.py's weak scaling, measured on one GPU (developer tool).
+BT_SLICES=1 switches sample slicing off for the A/B."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+import torch
+import bendy_tracer_amd as b
+w, h = 1920, 1080
+name = sys.argv[1] if len(sys.argv) > 1 else 'scene'
+sc = b.Scene.load(f'scenes/{name}.json.gz'); cam = sc.find_by_tag('camera'); sc.set_camera_aspect(cam, w / h)
+tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
+for mode in ('auto', '1'):
+    if mode == 'auto':
+        os.environ.pop('BT_SLICES', None)
+    else:
+        os.environ['BT_SLICES'] = mode
+    for world in (1, 2, 4, 8):
+        spp = 64 * world
+        for rank in sorted({0, world - 1}):
+            shard = b.new_shard(w, h, world); ks = []
+            for it in range(4):
+                tr.render_shard(sc, cam, b.RenderConfig.with_samples(spp), shard, w, h, rank, world, sample_base=it * spp)
+                torch.cuda.synchronize()
+                ks.append(sc.last_stats().kernel_ms)
+            st = sc.last_stats()
+            print(f'{name} slices={mode:>4} ({st.slices:2d}) world {world} rank {rank}: {spp} spp, kernel {min(ks[1:]):7.3f} ms, '
+                  f'{st.samples / min(ks[1:]) / 1e6:8.1f} Gsamples/s, seg/sample {st.segments/st.samples:.3f}', flush=True)
