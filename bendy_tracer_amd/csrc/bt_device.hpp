@@ -19,6 +19,14 @@ namespace {
 struct V3 { float x, y, z; };
 BT_DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 BT_DEV V3 mk(const BtV3 &a) { return mk(a.x, a.y, a.z); }
+// The primitive table is read through the constant address space (same memory, AS 4): loads from it are
+// invariant by definition, so a wave-uniform index always selects scalar (s_load) instructions -- even in
+// kernels that also store to global memory inside the loop (the sliced variant's parked samples), where the
+// compiler can no longer prove that a plain global load is not clobbered and falls back to per-lane loads.
+typedef const __attribute__((address_space(4))) BtPrim BtPrimK;
+typedef const __attribute__((address_space(4))) BtV3 BtV3K;
+BT_DEV V3 mk(BtV3K &a) { return mk(a.x, a.y, a.z); }
+BT_DEV BtPrimK *prim_table(const BtLaunch &P) { return (BtPrimK *)P.prims; }
 BT_DEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 BT_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 BT_DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
@@ -165,7 +173,8 @@ BT_DEV bool sphere_t(V3 o, V3 d, V3 c, float radius, float tmin, float tmax, flo
     return true;
 }
 // Rect::hit up to the containment test (rect.rs:110-137); q and p returned for pdf / face.
-BT_DEV bool rect_t(V3 o, V3 d, const BtPrim &R, float tmin, float tmax, bool strict, float &t_out, float &q_out,
+template <class PrimRef>
+BT_DEV bool rect_t(V3 o, V3 d, PrimRef &R, float tmin, float tmax, bool strict, float &t_out, float &q_out,
                    float &p_out) {
     V3 n = mk(R.c);
     float q = dot(d, n);
@@ -214,8 +223,9 @@ BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, i
     h.inside = false;
     h.p_neg = false;
     const int n = P.n_prims;
+    BtPrimK *prims = prim_table(P);
     for (int i = 0; i < n; ++i) {
-        const BtPrim &R = P.prims[i];           // wave-uniform index -> scalar loads
+        BtPrimK &R = prims[i];                  // wave-uniform index -> scalar loads
         if (R.kind == BT_PRIM_SPHERE) {
             V3 c = mk(R.c);
             bool taken = false;

@@ -45,7 +45,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #ifndef BT_LENS_BATCH
 #define BT_LENS_BATCH 8            // RK4 steps a lane marches per loop iteration before it yields
 #endif
-template <int OUTPUT, bool LENS>
+// SLICED: several waves share a pixel block's samples (BtLaunch::slices); a separate instantiation so that the
+// lane-owns-pixel build keeps its registers and has no global stores inside the loop.
+template <int OUTPUT, bool LENS, bool SLICED>
 __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
 
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
     // P.slices > 1: `slices` consecutive waves share an 8x8 pixel block, each walks a contiguous range of the
     // pixels' samples and parks the values in P.scratch (see BtLaunch); the `+=` happens in bt_accumulate_kernel.
     const uint32_t gwave_raw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t slices = (uint32_t)P.slices;
+    const uint32_t slices = SLICED ? (uint32_t)P.slices : 1u;
     const uint32_t gwave = gwave_raw / slices, slice = gwave_raw % slices;
     const uint32_t slot = gwave >> 2;                 // tile slot in launch order
     const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
     const V3 mcx = mk(P.cam_cx), mcy = mk(P.cam_cy), mcz = mk(P.cam_cz);
 
     V3 acc = mk(0.0f, 0.0f, 0.0f);
-    if (in_frame && slices == 1) acc = mk(out_px[0], out_px[1], out_px[2]);   // `*r += pixel.r` (buffer.rs:159-164)
+    if (in_frame && !SLICED) acc = mk(out_px[0], out_px[1], out_px[2]);   // `*r += pixel.r` (buffer.rs:159-164)
 
     // per-lane path state
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, -1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
         } else {
             value = first;
         }
-        if (slices == 1) {
+        if (!SLICED) {
             acc = acc + value;
         } else {
             *(float4 *)(P.scratch + ((size_t)k * P.n_local_px + local_px) * 4) = make_float4(value.x, value.y, value.z, 0.0f);
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
         }
     }
 
-    if (in_frame && slices == 1) {
+    if (in_frame && !SLICED) {
         out_px[0] = acc.x;
         out_px[1] = acc.y;
         out_px[2] = acc.z;
@@ -553,21 +555,22 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
     // kernel runs 5 waves/SIMD, and a loss when the LDS tables are large (cloud.json), so 256 it is.
     const unsigned block = BT_BLOCK_THREADS;
     dim3 g(grid * (256 / block) * (unsigned)P->slices), b(block);    // `slices` waves per 8x8 pixel block
-    if (P->lens_on) {
-        switch (output) {
-        case 0: hipLaunchKernelGGL((bt_render_kernel<0, true>), g, b, lds_bytes, stream, *P); break;
-        case 1: hipLaunchKernelGGL((bt_render_kernel<1, true>), g, b, lds_bytes, stream, *P); break;
-        case 2: hipLaunchKernelGGL((bt_render_kernel<2, true>), g, b, lds_bytes, stream, *P); break;
-        default: hipLaunchKernelGGL((bt_render_kernel<3, true>), g, b, lds_bytes, stream, *P); break;
-        }
-    } else {
-        switch (output) {
-        case 0: hipLaunchKernelGGL((bt_render_kernel<0, false>), g, b, lds_bytes, stream, *P); break;
-        case 1: hipLaunchKernelGGL((bt_render_kernel<1, false>), g, b, lds_bytes, stream, *P); break;
-        case 2: hipLaunchKernelGGL((bt_render_kernel<2, false>), g, b, lds_bytes, stream, *P); break;
-        default: hipLaunchKernelGGL((bt_render_kernel<3, false>), g, b, lds_bytes, stream, *P); break;
-        }
+    const bool sliced = P->slices > 1;
+#define BT_LAUNCH(O, L, S) hipLaunchKernelGGL((bt_render_kernel<O, L, S>), g, b, lds_bytes, stream, *P)
+#define BT_LAUNCH_OUT(L, S)                                                                                      \
+    switch (output) {                                                                                            \
+    case 0: BT_LAUNCH(0, L, S); break;                                                                           \
+    case 1: BT_LAUNCH(1, L, S); break;                                                                           \
+    case 2: BT_LAUNCH(2, L, S); break;                                                                           \
+    default: BT_LAUNCH(3, L, S); break;                                                                          \
     }
+    if (P->lens_on) {
+        if (sliced) { BT_LAUNCH_OUT(true, true) } else { BT_LAUNCH_OUT(true, false) }
+    } else {
+        if (sliced) { BT_LAUNCH_OUT(false, true) } else { BT_LAUNCH_OUT(false, false) }
+    }
+#undef BT_LAUNCH_OUT
+#undef BT_LAUNCH
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && P->slices > 1) {
         hipLaunchKernelGGL(bt_accumulate_kernel, dim3(grid), dim3(256), 0, stream, *P);
