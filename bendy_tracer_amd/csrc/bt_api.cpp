@@ -125,7 +125,7 @@ int ensure_device(bt_scene *s) {
     BT_HIP(s->d_lights.upload(s->flat.lights));
     BT_HIP(s->d_light_faces.upload(s->flat.light_faces));
     BT_HIP(s->d_density.upload(s->flat.density));
-    if (!s->d_counters) BT_HIP(hipMalloc((void **)&s->d_counters, 2 * sizeof(unsigned long long)));
+    if (!s->d_counters) BT_HIP(hipMalloc((void **)&s->d_counters, BT_N_COUNTERS * sizeof(unsigned long long)));
     if (!s->ev_start) BT_HIP(hipEventCreate(&s->ev_start));
     if (!s->ev_stop) BT_HIP(hipEventCreate(&s->ev_stop));
     s->device = dev;
@@ -258,7 +258,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         }
     }
 
-    BT_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), stream));
+    BT_HIP(hipMemsetAsync(s->d_counters, 0, BT_N_COUNTERS * sizeof(unsigned long long), stream));
     BT_HIP(hipEventRecord(s->ev_start, stream));
     // Two bit-identical kernels: the regrouping one (bt_kernels_sorted.hip, path state in LDS, lanes
     // re-sorted by event kind every iteration) and the lane-owns-pixel one (bt_kernels.hip).  The
@@ -540,8 +540,18 @@ int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {
     if (!scene || !out) return set_error(BT_ERR_INVALID_ARG, "null argument");
     if (scene->stats_pending) {
         BT_HIP(hipEventSynchronize(scene->ev_stop));
-        unsigned long long c[2] = {0, 0};
+        unsigned long long c[BT_N_COUNTERS] = {0, 0};
         BT_HIP(hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
+#ifdef BT_PROFILE
+        // developer build (-DBT_PROFILE): wave cycles per section of the render loop, see bt_kernels.hip
+        {
+            unsigned long long tot = 0;
+            for (int i = 2; i < BT_N_COUNTERS; ++i) tot += c[i];
+            fprintf(stderr, "[bt profile] section share of wave cycles:");
+            for (int i = 2; i < BT_N_COUNTERS; ++i) fprintf(stderr, " s%d=%.1f%%", i - 2, tot ? 100.0 * (double)c[i] / (double)tot : 0.0);
+            fprintf(stderr, "\n");
+        }
+#endif
         float ms = 0.0f;
         BT_HIP(hipEventElapsedTime(&ms, scene->ev_start, scene->ev_stop));
         scene->last.segments = c[0];

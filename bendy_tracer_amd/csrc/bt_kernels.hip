@@ -27,6 +27,16 @@
 #define BT_BLOCK_THREADS 256
 #endif
 
+// Developer build (-DBT_PROFILE): s_memtime stamps around the sections of the render loop, summed per wave into
+// counters[2..]; shares of wave cycles are printed by bt_scene_last_stats.  Not part of the product build.
+#ifdef BT_PROFILE
+#define BT_PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[BT_N_COUNTERS - 2] = {}
+#define BT_PROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define BT_PROF_DECL
+#define BT_PROF(i)
+#endif
+
 namespace {
 
 enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 };
@@ -146,7 +156,9 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
         k += 1;
     };
 
+    BT_PROF_DECL;
     while (k < total) {
+        BT_PROF(0);                                       // loop overhead / previous iteration's tail
         int ev = EV_GEN;
         // manifold of this iteration's hit (shading events only)
         V3 pos = ro, normal = mk(0, 0, 0);
@@ -244,6 +256,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
             }
         }
         pending = false;
+        BT_PROF(1);                                       // TRACE + hit classification
 
         // ---- the lane's one random event of this iteration (numerics contract N6) ----
         const uint32_t sample_index = sample0 + k;
@@ -254,6 +267,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
         const float r1 = uniform_sample(w1, 0.0f, P.tau_scale), r2 = uniform_sample(w2, 0.0f, P.one_scale);
         float sn, cs;
         sincos_bt(r1, sn, cs);
+        BT_PROF(2);                                       // Philox + shared sin/cos
 
         V3 new_o = pos, dir = rd;
         bool late_end = false;
@@ -298,6 +312,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
             have_first = false;
             first = mk(0, 0, 0);
             first_depth = __builtin_inff();
+            BT_PROF(3);                                   // camera ray
         } else {
             event += 1;
             // ---- direction sample in the local frame (math/distr.rs) ----
@@ -389,6 +404,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
             }
         }
 
+        BT_PROF(4);                                       // scatter direction / volume step
         // Ray::new normalizes (ray.rs:96-101); for the camera this is the last normalize of mod.rs:296-301
         const V3 nd = normalize(dir);
 
@@ -432,6 +448,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
             finish_sample();
             pending = true;
         }
+        BT_PROF(5);                                       // normalize, pdf weight (light_pdf), bookkeeping
     }
 
     if (in_frame && !SLICED) {
@@ -446,6 +463,10 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
             unsigned long long ls = wave_sum(lens_steps);
             if (lane == 0 && ls) atomicAdd(&P.counters[1], ls);
         }
+#ifdef BT_PROFILE
+        if (lane == 0)
+            for (int i = 0; i < BT_N_COUNTERS - 2; ++i) atomicAdd(&P.counters[2 + i], prof_acc[i]);
+#endif
     }
 }
 
