@@ -231,21 +231,37 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     const uint32_t grid = sharded ? (n_tiles + world - 1) / world : n_tiles;
 
-    // Few pixels but many samples per pixel (a rank's shard under weak scaling: 1/8 of the tiles at 8x the spp)
-    // means few, very long waves -- one round of the GPU, whose length is that of the heaviest wave (measured:
-    // 18.6 ms instead of 6.2 ms for the same samples, profiles/r01d/shard_slicing.log).  Slice the samples so the
-    // launch has the shape of a full frame; below ~32 samples per lane slicing does not pay (C2).
+    // Sample slicing (BtLaunch::slices): S slices of >= 16 samples each where the pixel count alone gives fewer
+    // than ~6 rounds of resident waves or the launch is long enough for its tail to matter; measured on MI355X
+    // (profiles/r01d): C3 6.26 -> ~4.9 ms with S = 4, a world-8 shard (512 spp) 20.3 -> ~5 ms with S = 16.
+    // Scratch = 16 B per sample of the launch; a render that would need more than BT_SCRATCH_CAP is issued as
+    // several launches over consecutive sample ranges (k launches of m samples == one launch of k * m samples).
+    const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
+    const uint64_t px_launch = (uint64_t)grid * BT_TILE_DIM * BT_TILE_DIM;
+    uint32_t chunk = (uint32_t)P.samples;                         // samples per launch
     P.slices = 1;
-    P.n_local_px = grid * BT_TILE_DIM * BT_TILE_DIM;
     P.scratch = nullptr;
     {
-        const uint64_t total_px = (uint64_t)P.samples * (uint64_t)(P.subsample_n * P.subsample_n);
-        const uint64_t waves = (uint64_t)grid * 4, want = 6 * 256 * 20;          // ~6 rounds of resident waves
-        uint64_t slices = waves >= want ? 1 : (want + waves - 1) / waves;
-        slices = std::min<uint64_t>({slices, total_px / 32, 32});
-        if (const char *e = getenv("BT_SLICES")) slices = std::min<uint64_t>(std::max(1, atoi(e)), std::max<uint64_t>(total_px, 1));   // A/B knob
-        const uint64_t need = (uint64_t)P.n_local_px * total_px * 4 * sizeof(float);
-        if (slices > 1 && need <= (4ull << 30)) {
+        const uint64_t cap = 8ull << 30;
+        auto pick = [&](uint64_t T) {
+            uint32_t S = 1;
+            while (S < 16 && T / (2 * S) >= 16) S *= 2;             // >= 16 samples per slice
+            const uint64_t waves = (uint64_t)grid * 4;             // too few pixels to fill the GPU: go down to 4 per slice
+            while (S < 16 && waves * S < 4 * 5120 && T / (2 * S) >= 4) S *= 2;
+            return S;
+        };
+        uint32_t S = pick((uint64_t)chunk * nn);
+        if (const char *e = getenv("BT_SLICES")) {                 // A/B knob: 1, 2, 4, 8, 16
+            const int v = atoi(e);
+            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) S = (uint32_t)v;
+        }
+        if (S > 1) {
+            const uint64_t per_sample = px_launch * nn * 4 * sizeof(float);
+            if (per_sample * chunk > cap) chunk = (uint32_t)std::max<uint64_t>(1, cap / per_sample);
+            if (chunk < (uint32_t)P.samples && !getenv("BT_SLICES")) S = pick((uint64_t)chunk * nn);
+        }
+        if (S > 1) {
+            const uint64_t need = px_launch * nn * chunk * 4 * sizeof(float);
             if (s->scratch_bytes < need) {
                 if (s->d_scratch) (void)hipFree(s->d_scratch);
                 s->d_scratch = nullptr;
@@ -253,8 +269,10 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
                 BT_HIP(hipMalloc((void **)&s->d_scratch, need));
                 s->scratch_bytes = need;
             }
-            P.slices = (int32_t)slices;
+            P.slices = (int32_t)S;
             P.scratch = s->d_scratch;
+        } else {
+            chunk = (uint32_t)P.samples;
         }
     }
 
@@ -273,11 +291,19 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     const bool can_sort = P.max_bounces < 250 && P.max_volume_bounces < 250 &&
                           s->flat.lds_bytes() + bt_sorted_state_bytes(output) <= 64 * 1024;
     const bool use_sorted = can_sort && variant == BT_KERNEL_SORTED && !P.lens_on;   // the lens lives in the lanes kernel
-    if (use_sorted) P.slices = 1;                 // the regrouping kernel owns whole pixels
-    if (use_sorted)
+    if (use_sorted) {                             // the regrouping kernel owns whole pixels
+        P.slices = 1;
         BT_HIP(bt_launch_render_sorted(&P, output, grid, s->flat.lds_bytes(), stream));
-    else
-        BT_HIP(bt_launch_render(&P, output, grid, s->flat.lds_bytes(), stream));
+    } else {
+        const uint32_t all = (uint32_t)P.samples, base = P.sample_base;
+        for (uint32_t done = 0; done < all; done += chunk) {
+            P.samples = (int32_t)std::min(chunk, all - done);
+            P.sample_base = base + done;
+            BT_HIP(bt_launch_render(&P, output, grid, s->flat.lds_bytes(), stream));
+        }
+        P.samples = (int32_t)all;
+        P.sample_base = base;
+    }
     BT_HIP(hipEventRecord(s->ev_stop, stream));
 
     // pixels actually owned by this rank

@@ -331,6 +331,24 @@ BT_DEV float density_sample(const BtVolume &vol, const float *density, V3 coord)
     return lerpf(z0, z1, tz);
 }
 
+// Pixel q of block `sub` of a 16x16 tile that is cut into 256 / pxb blocks (bt_render_kernel's mapping): blocks of
+// 256, 128 or 64 pixels are made of whole 8x8 quadrants, smaller ones are 8x4 (pxb 32) or 4x4 (pxb 16) pixels,
+// numbered row-major inside the tile.
+struct BlockPixel { uint32_t x, y; };
+BT_DEV BlockPixel block_pixel(uint32_t sub, uint32_t q, uint32_t pxb) {
+    BlockPixel r;
+    if (pxb >= 64) {
+        const uint32_t quad = (sub * pxb + q) >> 6;
+        r.x = ((quad & 1) << 3) | (q & 7);
+        r.y = ((quad >> 1) << 3) | ((q & 63) >> 3);
+    } else {
+        const uint32_t bw = pxb >= 32 ? 8u : 4u, nbx = 16u / bw;
+        r.x = (sub % nbx) * bw + q % bw;
+        r.y = (sub / nbx) * 4u + q / bw;
+    }
+    return r;
+}
+
 BT_DEV unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -23,10 +23,6 @@
 //   * no MFMA: there is no dense contraction on this path.
 #include "bt_device.hpp"
 
-#ifndef BT_BLOCK_THREADS
-#define BT_BLOCK_THREADS 256
-#endif
-
 // Developer build (-DBT_PROFILE): s_memtime stamps around the sections of the render loop, summed per wave into
 // counters[2..]; shares of wave cycles are printed by bt_scene_last_stats.  Not part of the product build.
 #ifdef BT_PROFILE
@@ -60,6 +56,8 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 template <int OUTPUT, bool LENS, bool SLICED>
 __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t s_waves_done;      // SLICED: waves of this workgroup that have parked all their samples
+    if (SLICED && threadIdx.x == 0) s_waves_done = 0;
 
     // ---- stage the per-lane lookup tables in LDS ----
     SceneLds S;
@@ -95,17 +93,20 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
     }
 
     // ---- tile / pixel mapping ----
-    // a workgroup is 1, 2 or 4 waves; four consecutive waves (in launch order) share a 16x16 tile
-    // P.slices > 1: `slices` consecutive waves share an 8x8 pixel block, each walks a contiguous range of the
-    // pixels' samples and parks the values in P.scratch (see BtLaunch); the `+=` happens in bt_accumulate_kernel.
-    const uint32_t gwave_raw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t slices = SLICED ? (uint32_t)P.slices : 1u;
-    const uint32_t gwave = gwave_raw / slices, slice = gwave_raw % slices;
-    const uint32_t slot = gwave >> 2;                 // tile slot in launch order
+    // A workgroup is 256 lanes = one pixel block x S sample slices (S = 1, 2, 4, 8, 16; S = 1 unless SLICED):
+    // the 16x16 tile `slot` is cut into S blocks of 256/S pixels, lane t works on pixel t % (256/S) of its block
+    // and on the slice t / (256/S) of that pixel's samples.  Blocks of >= 64 pixels are whole 8x8 quadrants (a wave
+    // = one quadrant, coherent camera rays); smaller ones are 8x4 / 4x4 pixels and a wave holds several slices.
+    const uint32_t NS = SLICED ? (uint32_t)P.slices : 1u;
+    const uint32_t pxb = 256u / NS;                    // pixels per block
+    const uint32_t bi = blockIdx.x;                    // block index in launch order
+    const uint32_t slot = bi / NS, sub = bi % NS;        // tile slot, block within the tile
     const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
     const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-    const uint32_t lane = threadIdx.x & 63, wave = gwave & 3;
-    const uint32_t lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t slice = threadIdx.x / pxb, pb = threadIdx.x % pxb;
+    const BlockPixel bp = block_pixel(sub, pb, pxb);
+    const uint32_t lx = bp.x, ly = bp.y;
     const uint32_t px = tx * BT_TILE_DIM + lx, py = ty * BT_TILE_DIM + ly;
     const bool in_frame = (ty < P.tiles_y) && (px < P.width) && (py < P.height);
     float *out_px = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + ly * BT_TILE_DIM + lx) * 4
@@ -113,10 +114,12 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
 
     const uint32_t pixel_index = py * P.width + px;
     const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
-    const uint32_t total_px = in_frame ? (uint32_t)P.samples * nn : 0u;          // samples of this pixel
-    const uint32_t k_begin = (uint32_t)(((unsigned long long)total_px * slice) / slices);
-    const uint32_t total = (uint32_t)(((unsigned long long)total_px * (slice + 1)) / slices);   // this lane's end
-    const uint32_t local_px = slot * (BT_TILE_DIM * BT_TILE_DIM) + (wave << 6) + lane;
+    const uint32_t T = (uint32_t)P.samples * nn;                                 // samples per pixel in this launch
+    const uint32_t total_px = in_frame ? T : 0u;
+    const uint32_t k_begin = (uint32_t)(((unsigned long long)total_px * slice) / NS);
+    const uint32_t total = (uint32_t)(((unsigned long long)total_px * (slice + 1)) / NS);       // this lane's end
+    // SLICED: sample k of block pixel pb is parked at scratch[(bi * T + k) * pxb + pb] (float4)
+    float4 *park = SLICED ? (float4 *)P.scratch + (size_t)bi * T * pxb + pb : nullptr;
     const uint32_t sample0 = P.sample_base * nn;
     const V3 mcx = mk(P.cam_cx), mcy = mk(P.cam_cy), mcz = mk(P.cam_cz);
 
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
         if (!SLICED) {
             acc = acc + value;
         } else {
-            *(float4 *)(P.scratch + ((size_t)k * P.n_local_px + local_px) * 4) = make_float4(value.x, value.y, value.z, 0.0f);
+            park[(size_t)k * pxb] = make_float4(value.x, value.y, value.z, 0.0f);
         }
         k += 1;
     };
@@ -456,6 +459,43 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
         out_px[1] = acc.y;
         out_px[2] = acc.z;
     }
+    if (SLICED) {
+        // The last wave of the workgroup to get here performs `*r += pixel.r` (buffer.rs:159-164) for every parked
+        // sample of the block's pixels, in sample order -- the additions the unsliced kernel performs in registers,
+        // in the same order.  The parked values were written by waves of this workgroup (same CU, same L1/L2), so
+        // workgroup-scope release / acquire is all the ordering that is needed.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t arrived = 0;
+        if (lane == 0) arrived = atomicAdd(&s_waves_done, 1u);
+        arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+        if (arrived == (blockDim.x >> 6) - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (uint32_t q = lane; q < pxb; q += 64) {
+                const BlockPixel b2 = block_pixel(sub, q, pxb);
+                const uint32_t qx = tx * BT_TILE_DIM + b2.x, qy = ty * BT_TILE_DIM + b2.y;
+                if (!((ty < P.tiles_y) && (qx < P.width) && (qy < P.height))) continue;
+                float *o = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + b2.y * BT_TILE_DIM + b2.x) * 4
+                                     : P.out + ((size_t)qy * P.width + qx) * 4;
+                const float4 *src = (const float4 *)P.scratch + (size_t)bi * T * pxb + q;
+                V3 sum = mk(o[0], o[1], o[2]);
+                uint32_t kk = 0;
+                for (; kk + 8 <= T; kk += 8) {             // eight loads in flight, additions strictly in order
+                    float4 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j) * pxb];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
+                }
+                for (; kk < T; ++kk) {
+                    const float4 v = src[(size_t)kk * pxb];
+                    sum = sum + mk(v.x, v.y, v.z);
+                }
+                o[0] = sum.x;
+                o[1] = sum.y;
+                o[2] = sum.z;
+            }
+        }
+    }
     if (P.counters) {
         unsigned long long s = wave_sum(segments);
         if (lane == 0 && s) atomicAdd(&P.counters[0], s);
@@ -468,31 +508,6 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
             for (int i = 0; i < BT_N_COUNTERS - 2; ++i) atomicAdd(&P.counters[2 + i], prof_acc[i]);
 #endif
     }
-}
-
-// Second pass of a sliced render: `*r += pixel.r` for every parked sample value, in sample order
-// (buffer.rs:159-164) -- the same additions, in the same order, as the unsliced kernel performs in registers.
-// scratch is sample-major, so a wave reads 1 KB contiguous per sample.
-__global__ __launch_bounds__(256) void bt_accumulate_kernel(BtLaunch P) {
-    const uint32_t slot = blockIdx.x;
-    const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
-    const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
-    const uint32_t px = tx * BT_TILE_DIM + lx, py = ty * BT_TILE_DIM + ly;
-    if (!((ty < P.tiles_y) && (px < P.width) && (py < P.height))) return;
-    float *out_px = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + ly * BT_TILE_DIM + lx) * 4
-                              : P.out + ((size_t)py * P.width + px) * 4;
-    const uint32_t total_px = (uint32_t)P.samples * (uint32_t)(P.subsample_n * P.subsample_n);
-    const float4 *s = (const float4 *)P.scratch + (slot * (BT_TILE_DIM * BT_TILE_DIM) + threadIdx.x);
-    V3 acc = mk(out_px[0], out_px[1], out_px[2]);
-    for (uint32_t k = 0; k < total_px; ++k) {
-        const float4 v = s[(size_t)k * P.n_local_px];
-        acc = acc + mk(v.x, v.y, v.z);
-    }
-    out_px[0] = acc.x;
-    out_px[1] = acc.y;
-    out_px[2] = acc.z;
 }
 
 // shard (tile-major, `world` ranks back to back) -> row-major frame; rgb AND alpha copied.
@@ -571,11 +586,8 @@ __global__ __launch_bounds__(256) void bt_preview_kernel(const float4 *rgba, uin
 // ---- host-side launchers (called from bt_api.cpp) ---------------------------------------------
 extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream) {
-    // grid = tiles to render; a tile may be split over several workgroups (BT_BLOCK_THREADS = 64 / 128 /
-    // 256).  Measured on MI355X (profiles/r01b/ab_block.log): no gain from smaller workgroups once the
-    // kernel runs 5 waves/SIMD, and a loss when the LDS tables are large (cloud.json), so 256 it is.
-    const unsigned block = BT_BLOCK_THREADS;
-    dim3 g(grid * (256 / block) * (unsigned)P->slices), b(block);    // `slices` waves per 8x8 pixel block
+    // grid = tiles to render; with sample slicing a tile is S workgroups (see the mapping in the kernel)
+    dim3 g(grid * (unsigned)P->slices), b(256);
     const bool sliced = P->slices > 1;
 #define BT_LAUNCH(O, L, S) hipLaunchKernelGGL((bt_render_kernel<O, L, S>), g, b, lds_bytes, stream, *P)
 #define BT_LAUNCH_OUT(L, S)                                                                                      \
@@ -592,12 +604,7 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
     }
 #undef BT_LAUNCH_OUT
 #undef BT_LAUNCH
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess && P->slices > 1) {
-        hipLaunchKernelGGL(bt_accumulate_kernel, dim3(grid), dim3(256), 0, stream, *P);
-        e = hipGetLastError();
-    }
-    return e;
+    return hipGetLastError();
 }
 extern "C" hipError_t bt_launch_unshard(const float *gathered, float *frame, uint32_t width, uint32_t height,
                                         uint32_t tiles_x, uint32_t tiles_y, uint32_t world, uint32_t tiles_per_rank,

@@ -121,12 +121,13 @@ struct BtLaunch {
     int32_t sharded;                  // 0: out = row-major frame; 1: out = this rank's shard
     float *out;
     unsigned long long *counters;     // [0] path segments, [1] lens RK4 steps
-    // Sample slicing (bt_api.cpp decides): when a launch has too few pixels to fill the GPU but many samples per
-    // pixel (a rank's shard under multi-GPU weak scaling), `slices` waves share each 8x8 pixel block, every
-    // sample's value is parked in scratch[sample][local pixel] (4 floats) and bt_accumulate_kernel performs the
-    // per-pixel `+=` in sample order afterwards -- same additions, same order, same bits.
-    int32_t slices;                   // >= 1
-    uint32_t n_local_px;              // grid * 256
+    // Sample slicing (bt_api.cpp decides).  With one lane per pixel a wave lives for all of its pixels' samples,
+    // which leaves a long ragged tail at the end of a launch and, for launches with few pixels and many samples (a
+    // rank's shard under multi-GPU weak scaling), not enough waves to fill the GPU.  With slices = S in {2,4,8,16} a
+    // workgroup is 256/S pixels x S slices of the samples; every sample's value is parked in
+    // scratch[(block * T + k) * (256/S) + pixel] (float4, T = samples * n^2) and the last wave of the workgroup to
+    // finish adds them to the frame in sample order -- same additions, same order, same bits as slices = 1.
+    int32_t slices;                   // 1 = a lane owns all samples of its pixel (no scratch)
     float *scratch;
     // lens EXTENSION (not in the reference, default off; include/bendy_hip.h bt_lens)
     int32_t lens_on;

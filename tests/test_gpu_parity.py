@@ -226,20 +226,41 @@ def test_sharded_render_matches_full_frame(bendy, world):
 
 # ---- sample slicing: few pixels x many samples per pixel (a rank's shard under weak scaling) ---------------------
 @pytest.mark.parametrize("name,w,h,spp,n,output", [
-    ("scene", 64, 48, 128, 0, 0),        # 12 tiles -> 4 slices of 32 samples
+    ("scene", 64, 48, 128, 0, 0),
     ("volume", 48, 32, 96, 0, 0),
     ("cornell2", 40, 24, 17, 2, 0),      # 68 rays per pixel, ragged frame, slice bounds not a multiple of n^2
-    ("scene", 64, 48, 64, 0, 3),         # AOV through the parked-sample pass
-    ("cloud", 32, 32, 1000, 0, 0),       # 31 slices, the cap
+    ("scene", 64, 48, 64, 0, 3),         # AOV through the parked samples
+    ("cloud", 32, 32, 1000, 0, 0),
+    ("scene", 200, 120, 9, 0, 0),        # 9 samples over 2 slices, ragged right / bottom tiles
 ])
 def test_sliced_render_matches_oracle(bendy, oracle, name, w, h, spp, n, output):
-    """bt_api.cpp slices the samples of a pixel over several waves when the launch has too few pixels to
-    fill the GPU, parks every sample's value and sums them in sample order afterwards: same bits."""
+    """bt_api.cpp slices the samples of a pixel over the lanes of a workgroup (BtLaunch::slices), parks every
+    sample's value and the last wave of the workgroup sums them in sample order: same bits."""
     buf, stats, _ = gpu_render(bendy, name, w, h, spp, n=n, output=output)
     assert stats.slices > 1
     it, seg = oracle_render(oracle, name, w, h, spp, n=n, output=output, recursive=0)
     assert stats.segments == seg
     assert np.array_equal(buf.numpy(), it)
+
+
+@pytest.mark.parametrize("slices", [1, 2, 4, 8, 16])
+def test_every_slice_count_gives_the_same_frame(bendy, oracle, monkeypatch, slices):
+    """BT_SLICES forces S (developer knob): each block shape (16x16 ... 4x4 pixels) must give the oracle's bits,
+    on a ragged frame, in the full-frame and in the sharded layout."""
+    import torch
+    monkeypatch.setenv("BT_SLICES", str(slices))
+    w, h, spp, world = 70, 41, 24, 3
+    buf, stats, _ = gpu_render(bendy, "cornell", w, h, spp)
+    assert stats.slices == slices
+    it, seg = oracle_render(oracle, "cornell", w, h, spp)
+    assert stats.segments == seg and np.array_equal(buf.numpy(), it)
+    sc, cam = gpu_scene(bendy, "cornell", w, h)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    shards = [_render_shard(bendy, tr, sc, cam, w, h, spp, r, world) for r in range(world)]
+    out = bendy.Buffer.new(w, h)
+    bendy.unshard(torch.cat(shards), out, world)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.numpy(), it)
 
 
 def test_sliced_render_adds_to_prefilled_buffer(bendy, oracle):
