@@ -57,7 +57,11 @@ template <int OUTPUT, bool LENS, bool SLICED>
 __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_waves_done;      // SLICED: waves of this workgroup that have parked all their samples
-    if (SLICED && threadIdx.x == 0) s_waves_done = 0;
+    __shared__ uint32_t s_next_item;       // SLICED: the workgroup's work queue (next unclaimed (pixel, sample) pair)
+    if (SLICED && threadIdx.x == 0) {
+        s_waves_done = 0;
+        s_next_item = 0;
+    }
 
     // ---- stage the per-lane lookup tables in LDS ----
     SceneLds S;
@@ -93,38 +97,47 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
     }
 
     // ---- tile / pixel mapping ----
-    // A workgroup is 256 lanes = one pixel block x S sample slices (S = 1, 2, 4, 8, 16; S = 1 unless SLICED):
-    // the 16x16 tile `slot` is cut into S blocks of 256/S pixels, lane t works on pixel t % (256/S) of its block
-    // and on the slice t / (256/S) of that pixel's samples.  Blocks of >= 64 pixels are whole 8x8 quadrants (a wave
-    // = one quadrant, coherent camera rays); smaller ones are 8x4 / 4x4 pixels and a wave holds several slices.
+    // !SLICED: a workgroup is one 16x16 tile, wave w = its 8x8 quadrant w, a lane owns one pixel and walks that
+    // pixel's samples in order (the per-pixel sum lives in `acc`).
+    // SLICED (BtLaunch::slices = NS in {2,4,8,16}): the tile is cut into NS blocks of pxb = 256/NS pixels and a
+    // workgroup owns one block: its pxb * T (pixel, sample) pairs are work items i = k * pxb + pixel, handed out
+    // through an LDS counter (one atomic per wave and iteration, see the loop) -- a lane whose path has ended takes
+    // the next item, so all 256 lanes stay busy until the block's samples run out, and 64 consecutive items are the
+    // same sample of neighbouring pixels (coherent camera rays).  Every sample's value is parked at scratch[(block * T + k) * pxb + pixel]; the last wave to finish adds
+    // them to the frame in sample order (end of the kernel).
     const uint32_t NS = SLICED ? (uint32_t)P.slices : 1u;
     const uint32_t pxb = 256u / NS;                    // pixels per block
     const uint32_t bi = blockIdx.x;                    // block index in launch order
-    const uint32_t slot = bi / NS, sub = bi % NS;        // tile slot, block within the tile
+    const uint32_t slot = bi / NS, sub = bi % NS;      // tile slot, block within the tile
     const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
     const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t slice = threadIdx.x / pxb, pb = threadIdx.x % pxb;
-    const BlockPixel bp = block_pixel(sub, pb, pxb);
-    const uint32_t lx = bp.x, ly = bp.y;
-    const uint32_t px = tx * BT_TILE_DIM + lx, py = ty * BT_TILE_DIM + ly;
-    const bool in_frame = (ty < P.tiles_y) && (px < P.width) && (py < P.height);
-    float *out_px = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + ly * BT_TILE_DIM + lx) * 4
-                              : P.out + ((size_t)py * P.width + px) * 4;
-
-    const uint32_t pixel_index = py * P.width + px;
     const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
-    const uint32_t T = (uint32_t)P.samples * nn;                                 // samples per pixel in this launch
-    const uint32_t total_px = in_frame ? T : 0u;
-    const uint32_t k_begin = (uint32_t)(((unsigned long long)total_px * slice) / NS);
-    const uint32_t total = (uint32_t)(((unsigned long long)total_px * (slice + 1)) / NS);       // this lane's end
-    // SLICED: sample k of block pixel pb is parked at scratch[(bi * T + k) * pxb + pb] (float4)
-    float4 *park = SLICED ? (float4 *)P.scratch + (size_t)bi * T * pxb + pb : nullptr;
+    const uint32_t T = (uint32_t)P.samples * nn;       // samples per pixel in this launch
     const uint32_t sample0 = P.sample_base * nn;
     const V3 mcx = mk(P.cam_cx), mcy = mk(P.cam_cy), mcz = mk(P.cam_cz);
 
+    // the lane's current pixel and sample: fixed pixel / k = 0, 1, ... when !SLICED, set by next_item() when SLICED
+    uint32_t px, py, pixel_index, k = 0;
+    float4 *park = nullptr;                            // SLICED: where the current sample's value goes
+    float *out_px = nullptr;
+    bool alive;
     V3 acc = mk(0.0f, 0.0f, 0.0f);
-    if (in_frame && !SLICED) acc = mk(out_px[0], out_px[1], out_px[2]);   // `*r += pixel.r` (buffer.rs:159-164)
+    const uint32_t n_items = SLICED ? pxb * T : 0u;
+    if (SLICED) {
+        px = py = pixel_index = 0;
+        alive = true;                                  // until the workgroup's queue is empty (see the loop)
+    } else {
+        const BlockPixel b = block_pixel(0, threadIdx.x, 256);
+        px = tx * BT_TILE_DIM + b.x;
+        py = ty * BT_TILE_DIM + b.y;
+        pixel_index = py * P.width + px;
+        out_px = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + b.y * BT_TILE_DIM + b.x) * 4
+                           : P.out + ((size_t)py * P.width + px) * 4;
+        alive = (ty < P.tiles_y) && (px < P.width) && (py < P.height);
+        if (alive) acc = mk(out_px[0], out_px[1], out_px[2]);            // `*r += pixel.r` (buffer.rs:159-164)
+    }
+    const bool in_frame = alive;                       // !SLICED: this lane's pixel exists
 
     // per-lane path state
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, -1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
     float first_depth = __builtin_inff();
     bool have_first = false;
     int bounce = 0, vbounce = 0, last_object = -1;
-    uint32_t event = 0, k = k_begin;
+    uint32_t event = 0;
     bool pending = true;               // the lane has no ray yet: its next event is the camera ray
     unsigned long long segments = 0, lens_steps = 0;
     LensState lens;                    // lens extension: the bent segment in progress (LENS builds only)
@@ -153,14 +166,14 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
         }
         if (!SLICED) {
             acc = acc + value;
+            k += 1;
         } else {
-            park[(size_t)k * pxb] = make_float4(value.x, value.y, value.z, 0.0f);
+            *park = make_float4(value.x, value.y, value.z, 0.0f);
         }
-        k += 1;
     };
 
     BT_PROF_DECL;
-    while (k < total) {
+    while (alive) {
         BT_PROF(0);                                       // loop overhead / previous iteration's tail
         int ev = EV_GEN;
         // manifold of this iteration's hit (shading events only)
@@ -253,12 +266,39 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
                     }
                 }
             }
-            if (ended) {
-                finish_sample();
-                if (k >= total) break;
-            }
+            if (ended) finish_sample();
         }
         pending = false;
+
+        // ---- a lane whose path has ended (or that has none yet) moves on to its next sample ----
+        if (!SLICED) {
+            if (ev == EV_GEN && k >= T) break;                            // this pixel is done
+        } else {
+            const unsigned long long need = __ballot(ev == EV_GEN);
+            if (need) {                                                   // one LDS atomic for the whole wave
+                const int leader = __ffsll((long long)need) - 1;
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&s_next_item, (uint32_t)__popcll(need));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                if (ev == EV_GEN) {
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                    const uint32_t i = base + below;
+                    if (i >= n_items) break;                              // the block's samples are all taken
+                    const uint32_t q = i & (pxb - 1);
+                    k = i / pxb;
+                    const BlockPixel b = block_pixel(sub, q, pxb);
+                    px = tx * BT_TILE_DIM + b.x;
+                    py = ty * BT_TILE_DIM + b.y;
+                    if (!((ty < P.tiles_y) && (px < P.width) && (py < P.height))) {
+                        pending = true;                                   // pixel outside the frame (edge tile): skip it
+                        continue;
+                    }
+                    pixel_index = py * P.width + px;
+                    park = (float4 *)P.scratch + ((size_t)bi * T + k) * pxb + q;
+                }
+            }
+        }
         BT_PROF(1);                                       // TRACE + hit classification
 
         // ---- the lane's one random event of this iteration (numerics contract N6) ----
@@ -280,10 +320,10 @@ __global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLau
             float u_sub = 0.0f, v_sub = 0.0f;
             if (P.subsample_n > 1) {
                 const uint32_t n = (uint32_t)P.subsample_n;
-                const uint32_t sub = k % (n * n);
+                const uint32_t subpx = k % (n * n);
                 const float width_sub = 1.0f / (float)n;
-                u_sub = (float)(sub % n) * width_sub;
-                v_sub = (float)(sub / n) * width_sub;
+                u_sub = (float)(subpx % n) * width_sub;
+                v_sub = (float)(subpx / n) * width_sub;
             }
             const float v0 = (float)py * P.pixel_height - 1.0f;
             const float u0 = (float)px * P.pixel_width - 1.0f;
