@@ -75,6 +75,9 @@ struct bt_scene {
     DeviceArray<BtLight> d_lights;
     DeviceArray<BtLightFace> d_light_faces;
     DeviceArray<float> d_density;
+    DeviceArray<int32_t> d_lens_prims;     // lens extension: rows of d_prims near the sphere of influence
+    bt_lens lens_prims_for{};              // the lens d_lens_prims was built for
+    bool lens_prims_valid = false;
     unsigned long long *d_counters = nullptr;
     float *d_scratch = nullptr;    // parked sample values of sliced renders
     size_t scratch_bytes = 0;
@@ -130,7 +133,52 @@ int ensure_device(bt_scene *s) {
     if (!s->ev_stop) BT_HIP(hipEventCreate(&s->ev_stop));
     s->device = dev;
     s->device_valid = true;
+    s->lens_prims_valid = false;
     return 0;
+}
+
+// Lens extension: rows of the primitive table whose surface can come within `reach` of the lens centre.
+// Conservative by construction (double arithmetic, bounding spheres for rects, 0.1 % slack): a row that is left
+// out cannot be touched by any point within `reach` of the centre.
+std::vector<int32_t> lens_candidates(const std::vector<BtPrim> &prims, const bt_lens &lens, double reach) {
+    std::vector<int32_t> rows;
+    const double cx = lens.centre[0], cy = lens.centre[1], cz = lens.centre[2];
+    reach *= 1.001;
+    for (size_t i = 0; i < prims.size(); ++i) {
+        const BtPrim &R = prims[i];
+        bool near_ = true;
+        if ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_SPHERE) {
+            const double d = std::sqrt((R.c.x - cx) * (R.c.x - cx) + (R.c.y - cy) * (R.c.y - cy) + (R.c.z - cz) * (R.c.z - cz));
+            near_ = std::fabs(d - (double)R.radius) <= reach + 1e-3 * (double)R.radius;    // the SURFACE is what is hit
+        } else {
+            // forward matrix = inverse of (icx, icy, icz); corners = t + M * (+-hw * ax +- hh * ay)
+            const double a[3][3] = {{R.icx.x, R.icy.x, R.icz.x}, {R.icx.y, R.icy.y, R.icz.y}, {R.icx.z, R.icy.z, R.icz.z}};
+            const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                               a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+            if (std::isfinite(det) && std::fabs(det) > 1e-30) {
+                double m[3][3];
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) {
+                        const int r1 = (c + 1) % 3, r2 = (c + 2) % 3, c1 = (r + 1) % 3, c2 = (r + 2) % 3;
+                        m[r][c] = (a[r1][c1] * a[r2][c2] - a[r1][c2] * a[r2][c1]) / det;
+                    }
+                const double hw = std::sqrt((double)R.w_sqr), hh = std::sqrt((double)R.h_sqr);
+                double bound = 0.0;
+                for (int sx = -1; sx <= 1; sx += 2)
+                    for (int sy = -1; sy <= 1; sy += 2) {
+                        const double l[3] = {sx * hw * R.ax.x + sy * hh * R.ay.x, sx * hw * R.ax.y + sy * hh * R.ay.y,
+                                             sx * hw * R.ax.z + sy * hh * R.ay.z};
+                        double wv[3];
+                        for (int r = 0; r < 3; ++r) wv[r] = m[r][0] * l[0] + m[r][1] * l[1] + m[r][2] * l[2];
+                        bound = std::max(bound, std::sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]));
+                    }
+                const double d = std::sqrt((R.t.x - cx) * (R.t.x - cx) + (R.t.y - cy) * (R.t.y - cy) + (R.t.z - cz) * (R.t.z - cz));
+                near_ = d - bound * 1.001 <= reach;
+            }
+        }
+        if (near_) rows.push_back((int32_t)i);
+    }
+    return rows;
 }
 
 // ChunkConfig::with_configs (mod.rs:217-229) + camera setup (mod.rs:244-267)
@@ -209,6 +257,22 @@ int fill_launch(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt
     P.lens_step = s->lens.step;
     P.lens_radius = s->lens.radius;
     P.lens_max_steps = (int32_t)s->lens.max_steps;
+    P.lens_prims = nullptr;
+    P.n_lens_prims = 0;
+    P.lens_margin = 0.0f;
+    if (s->lens_on) {
+        // |v| <= sqrt(1 + rs h^2 / r^3) <= 2.8 along any geodesic that started with |v| = 1 (h^2 <= 6.75 rs^2 for the
+        // captured ones, r >= rs), so a chord is at most ~2.8 steps long; longer ones (never seen) fall back to the
+        // full table in the kernel
+        P.lens_margin = 3.0f * s->lens.step;
+        if (!s->lens_prims_valid || std::memcmp(&s->lens_prims_for, &s->lens, sizeof(bt_lens)) != 0) {
+            BT_HIP(s->d_lens_prims.upload(lens_candidates(f.prims, s->lens, (double)s->lens.radius + (double)P.lens_margin)));
+            s->lens_prims_for = s->lens;
+            s->lens_prims_valid = true;
+        }
+        P.lens_prims = s->d_lens_prims.ptr;
+        P.n_lens_prims = (int32_t)s->d_lens_prims.count;
+    }
     return 0;
 }
 

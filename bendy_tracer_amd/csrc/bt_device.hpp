@@ -216,6 +216,37 @@ struct HitRec {
 // try_hit (mod.rs:389-402) and try_hit_volume (mod.rs:404-427) in one loop: in normal mode
 // last_object is -1 and the clip is [clip_min, clip_max]; while marching it is the marched
 // object and the clip is [0, volume_step].
+BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int last_object, HitRec &h) {
+    BtPrimK &R = prims[i];                      // wave-uniform index -> scalar loads
+    if (R.kind == BT_PRIM_SPHERE) {
+        V3 c = mk(R.c);
+        bool taken = false;
+        if (R.object == last_object) {          // Sphere::hit_volumetric (sphere.rs:150-166)
+            V3 e = (o + d * h.t) - c;
+            if (len2(e) <= R.radius * R.radius) {
+                h.prim = i;
+                h.inside = true;
+                taken = true;
+            }
+        }
+        if (!taken) {
+            float t;
+            if (sphere_t(o, d, c, R.radius, tmin, h.t, t)) {
+                h.t = t;
+                h.prim = i;
+                h.inside = false;
+            }
+        }
+    } else {
+        float t, q, p;
+        if (rect_t(o, d, R, tmin, h.t, (R.kind & BT_PRIM_STRICT) != 0, t, q, p)) {
+            h.t = t;
+            h.prim = i;
+            h.inside = false;
+            h.p_neg = p < 0.0f;
+        }
+    }
+}
 BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object) {
     HitRec h;
     h.t = tmax;
@@ -224,37 +255,19 @@ BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, i
     h.p_neg = false;
     const int n = P.n_prims;
     BtPrimK *prims = prim_table(P);
-    for (int i = 0; i < n; ++i) {
-        BtPrimK &R = prims[i];                  // wave-uniform index -> scalar loads
-        if (R.kind == BT_PRIM_SPHERE) {
-            V3 c = mk(R.c);
-            bool taken = false;
-            if (R.object == last_object) {      // Sphere::hit_volumetric (sphere.rs:150-166)
-                V3 e = (o + d * h.t) - c;
-                if (len2(e) <= R.radius * R.radius) {
-                    h.prim = i;
-                    h.inside = true;
-                    taken = true;
-                }
-            }
-            if (!taken) {
-                float t;
-                if (sphere_t(o, d, c, R.radius, tmin, h.t, t)) {
-                    h.t = t;
-                    h.prim = i;
-                    h.inside = false;
-                }
-            }
-        } else {
-            float t, q, p;
-            if (rect_t(o, d, R, tmin, h.t, (R.kind & BT_PRIM_STRICT) != 0, t, q, p)) {
-                h.t = t;
-                h.prim = i;
-                h.inside = false;
-                h.p_neg = p < 0.0f;
-            }
-        }
-    }
+    for (int i = 0; i < n; ++i) intersect_row(prims, i, o, d, tmin, last_object, h);
+    return h;
+}
+// Lens extension: the same loop over the rows listed in P.lens_prims (ascending, so ties resolve as in intersect()).
+BT_DEV HitRec intersect_listed(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax) {
+    HitRec h;
+    h.t = tmax;
+    h.prim = -1;
+    h.inside = false;
+    h.p_neg = false;
+    BtPrimK *prims = prim_table(P);
+    const __attribute__((address_space(4))) int32_t *rows = (const __attribute__((address_space(4))) int32_t *)P.lens_prims;
+    for (int j = 0; j < P.n_lens_prims; ++j) intersect_row(prims, rows[j], o, d, tmin, -1, h);
     return h;
 }
 
@@ -440,7 +453,12 @@ BT_DEV int lens_advance(const BtLaunch &P, V3 &x, V3 &v, LensState &st, HitRec &
             const float len = sqrtf(len2(chord));
             const V3 dirn = chord * (1.0f / len);
             const float seg = fminf(len, st.remaining);
-            h = intersect(P, x, dirn, st.first ? P.clip_min : 0.0f, seg, -1);
+            // the chord starts within lens_radius of the centre: if it is no longer than lens_margin only the listed
+            // rows can be touched (BtLaunch::lens_prims)
+            if (len <= P.lens_margin)
+                h = intersect_listed(P, x, dirn, st.first ? P.clip_min : 0.0f, seg);
+            else
+                h = intersect(P, x, dirn, st.first ? P.clip_min : 0.0f, seg, -1);
             if (h.prim >= 0) {
                 v = dirn;
                 return 1;

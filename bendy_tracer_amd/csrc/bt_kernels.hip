@@ -47,6 +47,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #ifndef BT_WAVES_PER_SIMD
 #define BT_WAVES_PER_SIMD 5
 #endif
+#ifndef BT_WAVES_PER_SIMD_LENS
+#define BT_WAVES_PER_SIMD_LENS 4       // the lens builds carry the RK4 state: 128 VGPRs, no scratch
+#endif
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
 #ifndef BT_LENS_BATCH
 #define BT_LENS_BATCH 8            // RK4 steps a lane marches per loop iteration before it yields
@@ -54,7 +57,7 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // SLICED: several waves share a pixel block's samples (BtLaunch::slices); a separate instantiation so that the
 // lane-owns-pixel build keeps its registers and has no global stores inside the loop.
 template <int OUTPUT, bool LENS, bool SLICED>
-__global__ __launch_bounds__(256, BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
+__global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_waves_done;      // SLICED: waves of this workgroup that have parked all their samples
     __shared__ uint32_t s_next_item;       // SLICED: the workgroup's work queue (next unclaimed (pixel, sample) pair)

@@ -134,4 +134,11 @@ struct BtLaunch {
     BtV3 lens_c;
     float lens_rs, lens_step, lens_radius;
     int32_t lens_max_steps;
+    // primitives that can be met inside the lens' sphere of influence: those whose surface comes within
+    // lens_radius + lens_margin of lens_c (ascending rows of `prims`; bt_api.cpp lens_candidates).  A chord of the
+    // RK4 march that starts inside the sphere and is no longer than lens_margin cannot touch any other primitive,
+    // so only these rows are tested for it -- an optimisation that cannot change a result.
+    const int32_t *lens_prims;
+    int32_t n_lens_prims;
+    float lens_margin;
 };
