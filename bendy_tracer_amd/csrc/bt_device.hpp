@@ -64,9 +64,12 @@ BT_DEV void sincos_bt(float x, float &s, float &c) {
 
 // ---- Philox4x32-10 (numerics contract N6) --------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
+#ifndef BT_PHILOX_ROUNDS
+#define BT_PHILOX_ROUNDS 10        // the numerics contract; other values only for timing experiments
+#endif
 BT_DEV U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < BT_PHILOX_ROUNDS; ++i) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;

@@ -42,10 +42,11 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // --------------------------------------------------------------------------------------------
 // The render kernel.  OUTPUT: 0 Full, 1 Albedo, 2 Normal, 3 Depth (tracer/mod.rs:108-115).
 // Block = 256 threads = one 16x16 pixel tile (BT_TILE); wave w covers the 8x8 quadrant w.
-// 5 waves per SIMD caps the allocation at 96 VGPRs: 95 used, no scratch, +6-8 % over the
-// unconstrained 104-VGPR build (profiles/r01b/ab_matrix1.log); 6 waves starts to spill.
+// 6 waves per SIMD caps the allocation at 80 VGPRs (6 dwords of scratch per lane, outside the hot blocks):
+// measured best once the camera block stopped living in SGPRs (profiles/r01d/ab_w678.log: C3 4.69 / 4.52 / 4.77 /
+// 5.48 ms at 5 / 6 / 7 / 8 waves; Cornell 15.6 / 15.0 / 14.7 / 14.6); round 1b had settled on 5 (96 VGPRs).
 #ifndef BT_WAVES_PER_SIMD
-#define BT_WAVES_PER_SIMD 5
+#define BT_WAVES_PER_SIMD 6
 #endif
 #ifndef BT_WAVES_PER_SIMD_LENS
 #define BT_WAVES_PER_SIMD_LENS 4       // the lens builds carry the RK4 state: 128 VGPRs, no scratch
@@ -118,7 +119,6 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
     const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
     const uint32_t T = (uint32_t)P.samples * nn;       // samples per pixel in this launch
     const uint32_t sample0 = P.sample_base * nn;
-    const V3 mcx = mk(P.cam_cx), mcy = mk(P.cam_cy), mcz = mk(P.cam_cz);
 
     // the lane's current pixel and sample: fixed pixel / k = 0, 1, ... when !SLICED, set by next_item() when SLICED
     uint32_t px, py, pixel_index, k = 0;
@@ -328,26 +328,34 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                 u_sub = (float)(subpx % n) * width_sub;
                 v_sub = (float)(subpx / n) * width_sub;
             }
-            const float v0 = (float)py * P.pixel_height - 1.0f;
-            const float u0 = (float)px * P.pixel_width - 1.0f;
-            const float u_offset = u_sub * P.pixel_width + uniform_sample(u.x, P.jitter_u_lo, P.jitter_u_scale);
-            const float v_offset = v_sub * P.pixel_height + uniform_sample(u.y, P.jitter_v_lo, P.jitter_v_scale);
+            // The camera block of the launch parameters (~30 dwords) is read from the kernarg segment HERE, through
+            // a pointer the compiler cannot see through: otherwise it hoists the loads into the prologue, where
+            // they live in SGPRs across the whole loop and push other values out into spills.
+            typedef const __attribute__((address_space(4))) BtLaunch BtLaunchK;
+            BtLaunchK *C = (BtLaunchK *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(C));
+            const V3 mcx = mk(C->cam_cx.x, C->cam_cx.y, C->cam_cx.z), mcy = mk(C->cam_cy.x, C->cam_cy.y, C->cam_cy.z),
+                     mcz = mk(C->cam_cz.x, C->cam_cz.y, C->cam_cz.z);
+            const float v0 = (float)py * C->pixel_height - 1.0f;
+            const float u0 = (float)px * C->pixel_width - 1.0f;
+            const float u_offset = u_sub * C->pixel_width + uniform_sample(u.x, C->jitter_u_lo, C->jitter_u_scale);
+            const float v_offset = v_sub * C->pixel_height + uniform_sample(u.y, C->jitter_v_lo, C->jitter_v_scale);
             const float uu = u0 + u_offset, vv = v0 + v_offset;
-            const float yrot = P.xfov * 0.5f * -uu;
-            const float xrot = P.yfov * 0.5f * -vv;
+            const float yrot = C->xfov * 0.5f * -uu;
+            const float xrot = C->yfov * 0.5f * -vv;
             float sy, cy, sx, cx;
             sincos_bt(yrot, sy, cy);
             sincos_bt(xrot, sx, cx);
             const V3 d_cam = mk(-(cx * sy), sx, -(cx * cy));
             // Affine3A * Ray: origin = translation + 0; direction = normalize(normalize_or_zero(M*d)),
             // the outer normalize being the shared one below
-            new_o = mk(P.cam_t) + mk(0.0f, 0.0f, 0.0f);
+            new_o = mk(C->cam_t.x, C->cam_t.y, C->cam_t.z) + mk(0.0f, 0.0f, 0.0f);
             dir = normalize_or_zero(xf_vector(mcx, mcy, mcz, d_cam));
-            if (P.has_focus) {                        // mod.rs:286-299; disk angle = r1, radius = r2
+            if (C->has_focus) {                       // mod.rs:286-299; disk angle = r1, radius = r2
                 const V3 d1 = normalize(dir);
-                const V3 defocus = (mk(P.disk_x) * cs + mk(P.disk_y) * sn) * r2;
-                const V3 defocus_offset = xf_vector(mcx, mcy, mcz, defocus * P.aperture);
-                const float frac_f_z = P.focus / fabsf(d_cam.z);
+                const V3 defocus = (mk(C->disk_x.x, C->disk_x.y, C->disk_x.z) * cs + mk(C->disk_y.x, C->disk_y.y, C->disk_y.z) * sn) * r2;
+                const V3 defocus_offset = xf_vector(mcx, mcy, mcz, defocus * C->aperture);
+                const float frac_f_z = C->focus / fabsf(d_cam.z);
                 new_o = new_o + defocus_offset;
                 dir = d1 * frac_f_z - defocus_offset;
             }
