@@ -176,9 +176,39 @@ BT_DEV bool sphere_t(V3 o, V3 d, V3 c, float radius, float tmin, float tmax, flo
     return true;
 }
 // Rect::hit up to the containment test (rect.rs:110-137); q and p returned for pdf / face.
+// Containment test of an axis-aligned rect (BT_PRIM_RECT_AAN) for the plane with normal axis W: A, B are the two
+// in-plane axes in ascending order; Rect.x is one of them (aa_u), which decides which extent limits which.
+#define BT_COMP(v, i) ((i) == 0 ? (v).x : ((i) == 1 ? (v).y : (v).z))
+template <int W, class PrimRef>
+BT_DEV bool rect_aan_t(V3 o, V3 d, PrimRef &R, float tmin, float tmax, bool strict, float &t_out, float &q_out, float &p_out) {
+    constexpr int A = W == 0 ? 1 : 0, B = W == 2 ? 1 : 2;
+    const float dq = BT_COMP(d, W);
+    if (fabsf(dq) <= 1e-5f) return false;
+    const float dp = BT_COMP(R.t, W) - BT_COMP(o, W);
+    const float t = dp / dq;                      // == dot(t - o, n) / dot(d, n), the signs of n cancel exactly
+    if (t < tmin || t > tmax) return false;
+    if (strict && !(t < tmax)) return false;
+    const float la = (BT_COMP(o, A) + BT_COMP(d, A) * t) + BT_COMP(R.it, A);
+    const float lb = (BT_COMP(o, B) + BT_COMP(d, B) * t) + BT_COMP(R.it, B);
+    const bool u_is_a = R.aa_u == A;
+    const float lim_a = u_is_a ? R.w_sqr : R.h_sqr, lim_b = u_is_a ? R.h_sqr : R.w_sqr;
+    if (!(la * la <= lim_a && lb * lb <= lim_b)) return false;
+    const float sgn = BT_COMP(R.c, W);            // +-1
+    t_out = t;
+    q_out = dq * sgn;
+    p_out = dp * sgn;
+    return true;
+}
+// Rect::hit up to the containment test (rect.rs:110-137); q and p returned for pdf / face.
 template <class PrimRef>
 BT_DEV bool rect_t(V3 o, V3 d, PrimRef &R, float tmin, float tmax, bool strict, float &t_out, float &q_out,
                    float &p_out) {
+    if ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_RECT_AAN) {
+        const int w = R.aa_w;
+        if (w == 0) return rect_aan_t<0>(o, d, R, tmin, tmax, strict, t_out, q_out, p_out);
+        if (w == 1) return rect_aan_t<1>(o, d, R, tmin, tmax, strict, t_out, q_out, p_out);
+        return rect_aan_t<2>(o, d, R, tmin, tmax, strict, t_out, q_out, p_out);
+    }
     V3 n = mk(R.c);
     float q = dot(d, n);
     if (fabsf(q) <= 1e-5f) return false;
@@ -219,9 +249,11 @@ struct HitRec {
 // try_hit (mod.rs:389-402) and try_hit_volume (mod.rs:404-427) in one loop: in normal mode
 // last_object is -1 and the clip is [clip_min, clip_max]; while marching it is the marched
 // object and the clip is [0, volume_step].
+// RECTS = false: the scene holds spheres only (bt_api.cpp checks), all rect code drops out of the build.
+template <bool RECTS = true>
 BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int last_object, HitRec &h) {
     BtPrimK &R = prims[i];                      // wave-uniform index -> scalar loads
-    if (R.kind == BT_PRIM_SPHERE) {
+    if (!RECTS || R.kind == BT_PRIM_SPHERE) {
         V3 c = mk(R.c);
         bool taken = false;
         if (R.object == last_object) {          // Sphere::hit_volumetric (sphere.rs:150-166)
@@ -250,6 +282,7 @@ BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int las
         }
     }
 }
+template <bool RECTS = true>
 BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object) {
     HitRec h;
     h.t = tmax;
@@ -258,10 +291,11 @@ BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, i
     h.p_neg = false;
     const int n = P.n_prims;
     BtPrimK *prims = prim_table(P);
-    for (int i = 0; i < n; ++i) intersect_row(prims, i, o, d, tmin, last_object, h);
+    for (int i = 0; i < n; ++i) intersect_row<RECTS>(prims, i, o, d, tmin, last_object, h);
     return h;
 }
 // Lens extension: the same loop over the rows listed in P.lens_prims (ascending, so ties resolve as in intersect()).
+template <bool RECTS = true>
 BT_DEV HitRec intersect_listed(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax) {
     HitRec h;
     h.t = tmax;
@@ -270,25 +304,26 @@ BT_DEV HitRec intersect_listed(const BtLaunch &P, V3 o, V3 d, float tmin, float 
     h.p_neg = false;
     BtPrimK *prims = prim_table(P);
     const __attribute__((address_space(4))) int32_t *rows = (const __attribute__((address_space(4))) int32_t *)P.lens_prims;
-    for (int j = 0; j < P.n_lens_prims; ++j) intersect_row(prims, rows[j], o, d, tmin, -1, h);
+    for (int j = 0; j < P.n_lens_prims; ++j) intersect_row<RECTS>(prims, rows[j], o, d, tmin, -1, h);
     return h;
 }
 
 // Object::pdf of a light (object/mod.rs:154-166; sphere.rs:44-61, rect.rs:92-108,
 // cuboid.rs:56-81); 0 when the ray misses it (material.rs:313-316 unwrap_or_default).
+template <bool RECTS = true>
 BT_DEV float light_pdf(const BtLaunch &P, const BtLight &Lt, const SceneLds &S, V3 o, V3 d) {
     if (Lt.kind == BT_LIGHT_SPHERE) {
         float t;
         if (!sphere_t(o, d, mk(Lt.centre), Lt.radius, P.clip_min, P.clip_max, t)) return 0.0f;
         return (t * t) / Lt.shadow;
     }
-    if (Lt.kind == BT_LIGHT_RECT) {
+    if (RECTS && Lt.kind == BT_LIGHT_RECT) {
         float t, q, p;
         if (!rect_t(o, d, P.prims[Lt.prim_first], P.clip_min, P.clip_max, false, t, q, p)) return 0.0f;
         float shadow = S.faces[Lt.face_first].area * fabsf(q);
         return (t * t) / shadow;
     }
-    if (Lt.kind == BT_LIGHT_CUBOID) {
+    if (RECTS && Lt.kind == BT_LIGHT_CUBOID) {
         float best_t = P.clip_max, best_q = 0.0f;
         int best = -1;
         for (int f = 0; f < Lt.prim_count; ++f) {
@@ -429,6 +464,7 @@ BT_DEV void lens_begin(const BtLaunch &P, LensState &st) {
 // again), 1 = hit (h = hit on the chord (x, v), which are updated to that chord), 0 = miss ((x, v) = the ray
 // that reaches the root), -1 = captured by the horizon.  st.travelled = path length before the returned
 // chord.  The arithmetic and its order are those of lens_trace() in oracle/bt_oracle.c.
+template <bool RECTS = true>
 BT_DEV int lens_advance(const BtLaunch &P, V3 &x, V3 &v, LensState &st, HitRec &h, int budget, unsigned long long &steps) {
     const V3 c = mk(P.lens_c);
     const float R2 = P.lens_radius * P.lens_radius, rs2 = P.lens_rs * P.lens_rs;
@@ -446,7 +482,7 @@ BT_DEV int lens_advance(const BtLaunch &P, V3 &x, V3 &v, LensState &st, HitRec &
                     if (te > 0.0f) t_enter = te;
                 }
                 const float seg = fminf(t_enter, st.remaining);
-                h = intersect(P, x, v, st.first ? P.clip_min : 0.0f, seg, -1);
+                h = intersect<RECTS>(P, x, v, st.first ? P.clip_min : 0.0f, seg, -1);
                 if (h.prim >= 0) return 1;
                 if (!(t_enter < st.remaining)) return 0;
                 x = x + v * t_enter;
@@ -474,9 +510,9 @@ BT_DEV int lens_advance(const BtLaunch &P, V3 &x, V3 &v, LensState &st, HitRec &
             // the chord starts within lens_radius of the centre: if it is no longer than lens_margin only the listed
             // rows can be touched (BtLaunch::lens_prims)
             if (len <= P.lens_margin)
-                h = intersect_listed(P, x, dirn, st.first ? P.clip_min : 0.0f, seg);
+                h = intersect_listed<RECTS>(P, x, dirn, st.first ? P.clip_min : 0.0f, seg);
             else
-                h = intersect(P, x, dirn, st.first ? P.clip_min : 0.0f, seg, -1);
+                h = intersect<RECTS>(P, x, dirn, st.first ? P.clip_min : 0.0f, seg, -1);
             if (h.prim >= 0) {
                 v = dirn;
                 return 1;

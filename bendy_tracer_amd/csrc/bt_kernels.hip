@@ -57,7 +57,8 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #endif
 // SLICED: several waves share a pixel block's samples (BtLaunch::slices); a separate instantiation so that the
 // lane-owns-pixel build keeps its registers and has no global stores inside the loop.
-template <int OUTPUT, bool LENS, bool SLICED>
+// RECTS = false: sphere-only scenes (scene.json, volume.json, cloud.json) run a build without any rect / cuboid code.
+template <int OUTPUT, bool LENS, bool SLICED, bool RECTS>
 __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_waves_done;      // SLICED: waves of this workgroup that have parked all their samples
@@ -204,14 +205,14 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                     bent = true;
                     segments += 1;
                 }
-                const int r = lens_advance(P, ro, rd, lens, h, BT_LENS_BATCH, lens_steps);
+                const int r = lens_advance<RECTS>(P, ro, rd, lens, h, BT_LENS_BATCH, lens_steps);
                 if (r == 2) continue;                     // still on its way: no event for this lane yet
                 bent = false;
                 captured = r < 0;
                 travelled = lens.travelled;
             } else {
                 segments += 1;
-                h = intersect(P, ro, rd, tmin, tmax, last_object);
+                h = intersect<RECTS>(P, ro, rd, tmin, tmax, last_object);
             }
             if (captured) {
                 ended = true;                         // swallowed by the horizon: the path returns black
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                 if (h.inside) {                       // generate_volume_manifold (sphere.rs:63-83)
                     inside = true;
                     vol_face = true;
-                } else if (pshape == BT_PRIM_SPHERE) { // generate_surface_manifold (sphere.rs:85-119)
+                } else if (!RECTS || pshape == BT_PRIM_SPHERE) { // generate_surface_manifold (sphere.rs:85-119)
                     V3 nrm = pos - prim_c;
                     nrm = mk(nrm.x / pl.radius, nrm.y / pl.radius, nrm.z / pl.radius);
                     front = dot(rd, nrm) < 0.0f;
@@ -398,9 +399,9 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                     V3 point;
                     if (Lt.kind == BT_LIGHT_SPHERE) {                     // sphere.rs:40-42
                         point = mk(Lt.centre) + v * Lt.radius;
-                    } else if (Lt.kind == BT_LIGHT_RECT) {
+                    } else if (RECTS && Lt.kind == BT_LIGHT_RECT) {
                         point = face_random_point(S.faces[Lt.face_first], u.z, u.w);
-                    } else if (Lt.kind == BT_LIGHT_CUBOID) {              // cuboid.rs:47-54
+                    } else if (RECTS && Lt.kind == BT_LIGHT_CUBOID) {     // cuboid.rs:47-54
                         const U4 e = philox(pixel_index, sample_index, event - 1u, 1u, P.seed_lo, P.seed_hi);
                         const float chosen = uniform_sample(e.x, 0.0f, Lt.total_scale);
                         int index = 0;
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
             if (ev == EV_DIFFUSE) {
                 const BtLight &Lt = S.lights[(int)__umulhi(u.x, (uint32_t)P.n_lights)];
                 const float pd = dot(normal, nd) * 0.318309886183790671538f;   // diffuse_pdf (:301-303)
-                const float plight = light_pdf(P, Lt, S, pos, nd);
+                const float plight = light_pdf<RECTS>(P, Lt, S, pos, nd);
                 const float p = lerpf(pd, plight, 0.5f);                  // :294-296
                 scatter = !(fabsf(p) <= 1e-5f);                           // Pdf::pdf (:279-286)
                 weight = pd / p;                                          // Material::pdf (:204) / shade.pdf
@@ -640,19 +641,23 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
     // grid = tiles to render; with sample slicing a tile is S workgroups (see the mapping in the kernel)
     dim3 g(grid * (unsigned)P->slices), b(256);
     const bool sliced = P->slices > 1;
-#define BT_LAUNCH(O, L, S) hipLaunchKernelGGL((bt_render_kernel<O, L, S>), g, b, lds_bytes, stream, *P)
-#define BT_LAUNCH_OUT(L, S)                                                                                      \
+    const bool rects = P->any_rects != 0;
+#define BT_LAUNCH(O, L, S, R) hipLaunchKernelGGL((bt_render_kernel<O, L, S, R>), g, b, lds_bytes, stream, *P)
+#define BT_LAUNCH_OUT(L, S, R)                                                                                   \
     switch (output) {                                                                                            \
-    case 0: BT_LAUNCH(0, L, S); break;                                                                           \
-    case 1: BT_LAUNCH(1, L, S); break;                                                                           \
-    case 2: BT_LAUNCH(2, L, S); break;                                                                           \
-    default: BT_LAUNCH(3, L, S); break;                                                                          \
+    case 0: BT_LAUNCH(0, L, S, R); break;                                                                        \
+    case 1: BT_LAUNCH(1, L, S, R); break;                                                                        \
+    case 2: BT_LAUNCH(2, L, S, R); break;                                                                        \
+    default: BT_LAUNCH(3, L, S, R); break;                                                                       \
     }
+#define BT_LAUNCH_RECTS(L, S)                                                                                    \
+    if (rects) { BT_LAUNCH_OUT(L, S, true) } else { BT_LAUNCH_OUT(L, S, false) }
     if (P->lens_on) {
-        if (sliced) { BT_LAUNCH_OUT(true, true) } else { BT_LAUNCH_OUT(true, false) }
+        if (sliced) { BT_LAUNCH_RECTS(true, true) } else { BT_LAUNCH_RECTS(true, false) }
     } else {
-        if (sliced) { BT_LAUNCH_OUT(false, true) } else { BT_LAUNCH_OUT(false, false) }
+        if (sliced) { BT_LAUNCH_RECTS(false, true) } else { BT_LAUNCH_RECTS(false, false) }
     }
+#undef BT_LAUNCH_RECTS
 #undef BT_LAUNCH_OUT
 #undef BT_LAUNCH
     return hipGetLastError();

@@ -344,6 +344,11 @@ FlatScene flatten_scene(const Scene &sc) {
             shape = BT_PRIM_RECT_AA;
             p.aa_u = au;
             p.aa_v = av;
+            const int aw = unit_axis(p.c);
+            if (au != av && aw >= 0 && aw != au && aw != av) {
+                shape = BT_PRIM_RECT_AAN;
+                p.aa_w = aw;
+            }
         }
         p.kind = shape | (strict ? BT_PRIM_STRICT : 0);
         fs.prims.push_back(p);

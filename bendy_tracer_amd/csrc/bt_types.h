@@ -19,9 +19,11 @@ struct BtV3 { float x, y, z; };
 // kind = shape | BT_PRIM_STRICT.  BT_PRIM_RECT_AA is a rect whose transform matrix is exactly the
 // identity and whose x / y axes are signed unit basis vectors: for it `M^-1 * pos + t'` and the two
 // projections of Rect::contains_point (rect.rs:74-80) reduce, bit for bit, to two component adds
-// and two squares (DESIGN.md "Kernel").  BT_PRIM_STRICT marks cuboid faces (`manifold.t < t`,
-// cuboid.rs:96).
-enum { BT_PRIM_SPHERE = 0, BT_PRIM_RECT = 1, BT_PRIM_RECT_AA = 2, BT_PRIM_SHAPE_MASK = 3, BT_PRIM_STRICT = 4 };
+// and two squares (DESIGN.md "Kernel").  BT_PRIM_RECT_AAN is such a rect whose world normal `c` is a signed unit
+// basis vector as well (component aa_w): then dot(d, n) = +-d[w] and dot(t - o, n) = +-(t[w] - o[w]) exactly, and
+// p / q = (t[w] - o[w]) / d[w] bit for bit -- the two dot products of rect.rs:120-124 reduce to one subtraction.
+// BT_PRIM_STRICT marks cuboid faces (`manifold.t < t`, cuboid.rs:96).
+enum { BT_PRIM_SPHERE = 0, BT_PRIM_RECT = 1, BT_PRIM_RECT_AA = 2, BT_PRIM_RECT_AAN = 3, BT_PRIM_SHAPE_MASK = 3, BT_PRIM_STRICT = 4 };
 struct BtPrim {
     int32_t kind;
     int32_t object;     // object index (ascending ObjectRef) -- `last_object` test, mod.rs:415
@@ -35,7 +37,7 @@ struct BtPrim {
     BtV3 icx; float h_sqr;   // inverse transform columns (rect.rs:134) ; half_height^2
     BtV3 icy; int32_t aa_u;     // BT_PRIM_RECT_AA: component index of Rect.x
     BtV3 icz; int32_t aa_v;     // BT_PRIM_RECT_AA: component index of Rect.y
-    BtV3 it;  float pad2;
+    BtV3 it;  int32_t aa_w;     // BT_PRIM_RECT_AAN: component index of the normal
     BtV3 ax;  float pad3;    // Rect.x (rect.rs:17)
     BtV3 ay;  float pad4;    // Rect.y (rect.rs:18)
 };
@@ -98,6 +100,7 @@ struct BtLaunch {
     const BtLightFace *light_faces;
     const float *density;
     int32_t n_prims, n_materials, n_volumes, n_lights, n_light_faces, n_density;
+    int32_t any_rects;                // 0: every row of `prims` is a sphere (selects the build without rect code)
     // root material (mod.rs:429-452), precomputed ColorData of sample_root
     BtV3 root_color, root_albedo;
     int32_t root_has_albedo;

@@ -67,14 +67,21 @@ def _expected_prims(o, sc):
         inv = o.Affine()
         o.lib().bto_affine_inverse(C.byref(tf), C.byref(inv))
         row = np.zeros(36, dtype=f32)
-        # shape 1 = general rect, 2 = axis-aligned rect (identity matrix, signed unit axes); | 4 = cuboid face
+        # shape 1 = general rect, 2 = axis-aligned rect (identity matrix, signed unit axes), 3 = such a rect whose
+        # world normal is a signed unit axis too; | 4 = cuboid face
         identity = [tf.cx.x, tf.cx.y, tf.cx.z, tf.cy.x, tf.cy.y, tf.cy.z, tf.cz.x, tf.cz.y, tf.cz.z] == [1, 0, 0, 0, 1, 0, 0, 0, 1]
         au, av = unit_axis(r.x), unit_axis(r.y)
         shape = 2 if (identity and au >= 0 and av >= 0) else 1
+        nrm = xf_vector(tf, v(r.z))
+        aw = unit_axis(o.V3(*[float(x) for x in nrm]))
+        if shape == 2 and au != av and aw >= 0 and aw not in (au, av):
+            shape = 3
         kind = shape | (4 if strict else 0)
-        if shape == 2:
+        if shape >= 2:
             row[19:20].view(np.int32)[:] = au
             row[23:24].view(np.int32)[:] = av
+        if shape == 3:
+            row[27:28].view(np.int32)[:] = aw
         row[:4].view(np.int32)[:] = [kind, oi, mats.index(r.material), -1]
         row[4:7] = xf_vector(tf, v(r.z))
         row[8:11] = v(tf.t)
