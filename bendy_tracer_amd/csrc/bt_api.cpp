@@ -206,8 +206,11 @@ int fill_launch(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt
     P.n_light_faces = (int32_t)f.light_faces.size();
     P.n_density = (int32_t)f.density.size();
     P.any_rects = 0;
-    for (const BtPrim &R : f.prims)
+    P.any_volumes = 0;
+    for (const BtPrim &R : f.prims) {
         if ((R.kind & BT_PRIM_SHAPE_MASK) != BT_PRIM_SPHERE) P.any_rects = 1;
+        if (R.volume >= 0) P.any_volumes = 1;
+    }
     P.root_color = f.root_color;
     P.root_albedo = f.root_albedo;
     P.root_has_albedo = f.root_has_albedo;

@@ -250,13 +250,14 @@ struct HitRec {
 // last_object is -1 and the clip is [clip_min, clip_max]; while marching it is the marched
 // object and the clip is [0, volume_step].
 // RECTS = false: the scene holds spheres only (bt_api.cpp checks), all rect code drops out of the build.
-template <bool RECTS = true>
+// VOLS = false: no sphere carries a volume, so nothing ever marches and the hit_volumetric test drops out.
+template <bool RECTS = true, bool VOLS = true>
 BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int last_object, HitRec &h) {
     BtPrimK &R = prims[i];                      // wave-uniform index -> scalar loads
     if (!RECTS || R.kind == BT_PRIM_SPHERE) {
         V3 c = mk(R.c);
         bool taken = false;
-        if (R.object == last_object) {          // Sphere::hit_volumetric (sphere.rs:150-166)
+        if (VOLS && R.object == last_object) {  // Sphere::hit_volumetric (sphere.rs:150-166)
             V3 e = (o + d * h.t) - c;
             if (len2(e) <= R.radius * R.radius) {
                 h.prim = i;
@@ -282,7 +283,7 @@ BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int las
         }
     }
 }
-template <bool RECTS = true>
+template <bool RECTS = true, bool VOLS = true>
 BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object) {
     HitRec h;
     h.t = tmax;
@@ -291,7 +292,7 @@ BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, i
     h.p_neg = false;
     const int n = P.n_prims;
     BtPrimK *prims = prim_table(P);
-    for (int i = 0; i < n; ++i) intersect_row<RECTS>(prims, i, o, d, tmin, last_object, h);
+    for (int i = 0; i < n; ++i) intersect_row<RECTS, VOLS>(prims, i, o, d, tmin, last_object, h);
     return h;
 }
 // Lens extension: the same loop over the rows listed in P.lens_prims (ascending, so ties resolve as in intersect()).
@@ -304,7 +305,7 @@ BT_DEV HitRec intersect_listed(const BtLaunch &P, V3 o, V3 d, float tmin, float 
     h.p_neg = false;
     BtPrimK *prims = prim_table(P);
     const __attribute__((address_space(4))) int32_t *rows = (const __attribute__((address_space(4))) int32_t *)P.lens_prims;
-    for (int j = 0; j < P.n_lens_prims; ++j) intersect_row<RECTS>(prims, rows[j], o, d, tmin, -1, h);
+    for (int j = 0; j < P.n_lens_prims; ++j) intersect_row<RECTS, false>(prims, rows[j], o, d, tmin, -1, h);
     return h;
 }
 
@@ -482,7 +483,7 @@ BT_DEV int lens_advance(const BtLaunch &P, V3 &x, V3 &v, LensState &st, HitRec &
                     if (te > 0.0f) t_enter = te;
                 }
                 const float seg = fminf(t_enter, st.remaining);
-                h = intersect<RECTS>(P, x, v, st.first ? P.clip_min : 0.0f, seg, -1);
+                h = intersect<RECTS, false>(P, x, v, st.first ? P.clip_min : 0.0f, seg, -1);
                 if (h.prim >= 0) return 1;
                 if (!(t_enter < st.remaining)) return 0;
                 x = x + v * t_enter;
@@ -512,7 +513,7 @@ BT_DEV int lens_advance(const BtLaunch &P, V3 &x, V3 &v, LensState &st, HitRec &
             if (len <= P.lens_margin)
                 h = intersect_listed<RECTS>(P, x, dirn, st.first ? P.clip_min : 0.0f, seg);
             else
-                h = intersect<RECTS>(P, x, dirn, st.first ? P.clip_min : 0.0f, seg, -1);
+                h = intersect<RECTS, false>(P, x, dirn, st.first ? P.clip_min : 0.0f, seg, -1);
             if (h.prim >= 0) {
                 v = dirn;
                 return 1;

@@ -58,7 +58,8 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // SLICED: several waves share a pixel block's samples (BtLaunch::slices); a separate instantiation so that the
 // lane-owns-pixel build keeps its registers and has no global stores inside the loop.
 // RECTS = false: sphere-only scenes (scene.json, volume.json, cloud.json) run a build without any rect / cuboid code.
-template <int OUTPUT, bool LENS, bool SLICED, bool RECTS>
+// VOLS = false: no sphere carries a volume (scene.json, the Cornell boxes): the march and Volume::shade drop out.
+template <int OUTPUT, bool LENS, bool SLICED, bool RECTS, bool VOLS>
 __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_waves_done;      // SLICED: waves of this workgroup that have parked all their samples
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
 
         if (!pending) {
             // ---- TRACE: try_hit (mod.rs:389-402) / try_hit_volume (mod.rs:404-427) ----
-            const bool marching = last_object >= 0;
+            const bool marching = VOLS && last_object >= 0;
             if (!marching) vbounce = 0;                               // sample() -> sample_volume(.., 0), mod.rs:335
             const float tmin = marching ? 0.0f : P.clip_min;
             const float tmax = marching ? P.volume_step : P.clip_max;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                 travelled = lens.travelled;
             } else {
                 segments += 1;
-                h = intersect<RECTS>(P, ro, rd, tmin, tmax, last_object);
+                h = intersect<RECTS, VOLS>(P, ro, rd, tmin, tmax, last_object);
             }
             if (captured) {
                 ended = true;                         // swallowed by the horizon: the path returns black
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                 hit_depth = LENS ? h.t + travelled : h.t;
                 pos = ro + rd * h.t;
                 bool vol_face = false;
-                if (h.inside) {                       // generate_volume_manifold (sphere.rs:63-83)
+                if (VOLS && h.inside) {               // generate_volume_manifold (sphere.rs:63-83)
                     inside = true;
                     vol_face = true;
                 } else if (!RECTS || pshape == BT_PRIM_SPHERE) { // generate_surface_manifold (sphere.rs:85-119)
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                     nrm = mk(nrm.x / pl.radius, nrm.y / pl.radius, nrm.z / pl.radius);
                     front = dot(rd, nrm) < 0.0f;
                     normal = front ? nrm : -nrm;
-                    vol_face = pl.volume >= 0;
+                    vol_face = VOLS && pl.volume >= 0;
                     vol_back = vol_face && !front;
                 } else {                              // rect.rs:138-142
                     front = h.p_neg;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                 else
                     base = refract(rd, normal, ior);
                 dir = base + v * M.roughness;
-            } else {
+            } else if (VOLS) {
                 // ---- Volume::shade (volume.rs:26-60) ----
                 const BtVolume &vol = S.volumes[vol_index];
                 const V3 hsz = mk(prim_radius, prim_radius, prim_radius);
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
 
         // sample() / sample_volumetric() return black past the limits (mod.rs:323-325, 352-354):
         // the path ends before its next TRACE
-        if (!late_end) late_end = last_object >= 0 ? (vbounce > P.max_volume_bounces) : (bounce > P.max_bounces);
+        if (!late_end) late_end = (VOLS && last_object >= 0) ? (vbounce > P.max_volume_bounces) : (bounce > P.max_bounces);
         if (late_end) {
             finish_sample();
             pending = true;
@@ -641,17 +642,20 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
     // grid = tiles to render; with sample slicing a tile is S workgroups (see the mapping in the kernel)
     dim3 g(grid * (unsigned)P->slices), b(256);
     const bool sliced = P->slices > 1;
-    const bool rects = P->any_rects != 0;
-#define BT_LAUNCH(O, L, S, R) hipLaunchKernelGGL((bt_render_kernel<O, L, S, R>), g, b, lds_bytes, stream, *P)
-#define BT_LAUNCH_OUT(L, S, R)                                                                                   \
+    // scene classes: bit 0 = some sphere carries a volume (volume.json, cloud.json), bit 1 = rects / cuboids present
+    // (the Cornell boxes); scene.json is class 0
+    const int cls = (P->any_rects ? 2 : 0) | (P->any_volumes ? 1 : 0);
+#define BT_LAUNCH(O, L, S, R, V) hipLaunchKernelGGL((bt_render_kernel<O, L, S, R, V>), g, b, lds_bytes, stream, *P)
+#define BT_LAUNCH_OUT(L, S, R, V)                                                                                \
     switch (output) {                                                                                            \
-    case 0: BT_LAUNCH(0, L, S, R); break;                                                                        \
-    case 1: BT_LAUNCH(1, L, S, R); break;                                                                        \
-    case 2: BT_LAUNCH(2, L, S, R); break;                                                                        \
-    default: BT_LAUNCH(3, L, S, R); break;                                                                       \
+    case 0: BT_LAUNCH(0, L, S, R, V); break;                                                                     \
+    case 1: BT_LAUNCH(1, L, S, R, V); break;                                                                     \
+    case 2: BT_LAUNCH(2, L, S, R, V); break;                                                                     \
+    default: BT_LAUNCH(3, L, S, R, V); break;                                                                    \
     }
 #define BT_LAUNCH_RECTS(L, S)                                                                                    \
-    if (rects) { BT_LAUNCH_OUT(L, S, true) } else { BT_LAUNCH_OUT(L, S, false) }
+    if (cls == 3) { BT_LAUNCH_OUT(L, S, true, true) } else if (cls == 2) { BT_LAUNCH_OUT(L, S, true, false) }      \
+    else if (cls == 1) { BT_LAUNCH_OUT(L, S, false, true) } else { BT_LAUNCH_OUT(L, S, false, false) }
     if (P->lens_on) {
         if (sliced) { BT_LAUNCH_RECTS(true, true) } else { BT_LAUNCH_RECTS(true, false) }
     } else {

@@ -101,6 +101,7 @@ struct BtLaunch {
     const float *density;
     int32_t n_prims, n_materials, n_volumes, n_lights, n_light_faces, n_density;
     int32_t any_rects;                // 0: every row of `prims` is a sphere (selects the build without rect code)
+    int32_t any_volumes;              // 0: no row carries a volume (selects the build without the march)
     // root material (mod.rs:429-452), precomputed ColorData of sample_root
     BtV3 root_color, root_albedo;
     int32_t root_has_albedo;
