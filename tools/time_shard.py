@@ -1,14 +1,15 @@
 """Per-rank kernel time under bench.py's weak scaling, measured on one GPU (developer tool).
-BT_SLICES=1 switches sample slicing off for the A/B."""
+usage: time_shard.py [scene] [BT_SLICES values, comma separated; "auto" = unset]"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
 import bendy_tracer_amd as b
 w, h = 1920, 1080
 name = sys.argv[1] if len(sys.argv) > 1 else 'scene'
+modes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['auto', '1']
 sc = b.Scene.load(f'scenes/{name}.json.gz'); cam = sc.find_by_tag('camera'); sc.set_camera_aspect(cam, w / h)
 tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
-for mode in ('auto', '1'):
+for mode in modes:
     if mode == 'auto':
         os.environ.pop('BT_SLICES', None)
     else:
