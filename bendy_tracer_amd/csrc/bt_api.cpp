@@ -312,7 +312,8 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     P.slices = 1;
     P.scratch = nullptr;
     {
-        const uint64_t cap = 8ull << 30;
+        uint64_t cap = 8ull << 30;
+        if (const char *e = getenv("BT_SCRATCH_CAP")) cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // bytes; tests
         auto pick = [&](uint64_t T) {
             uint32_t S = 1;
             while (S < 16 && T / (2 * S) >= 16) S *= 2;             // >= 16 samples per slice
@@ -336,9 +337,16 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
                 if (s->d_scratch) (void)hipFree(s->d_scratch);
                 s->d_scratch = nullptr;
                 s->scratch_bytes = 0;
-                BT_HIP(hipMalloc((void **)&s->d_scratch, need));
-                s->scratch_bytes = need;
+                if (hipMalloc((void **)&s->d_scratch, need) == hipSuccess) {
+                    s->scratch_bytes = need;
+                } else {
+                    (void)hipGetLastError();              // no room for the scratch: the lanes kernel needs none
+                    s->d_scratch = nullptr;
+                    S = 1;
+                }
             }
+        }
+        if (S > 1) {
             P.slices = (int32_t)S;
             P.scratch = s->d_scratch;
         } else {

@@ -263,6 +263,17 @@ def test_every_slice_count_gives_the_same_frame(bendy, oracle, monkeypatch, slic
     assert np.array_equal(out.numpy(), it)
 
 
+def test_render_deeper_than_the_scratch_is_split_into_launches(bendy, oracle, monkeypatch):
+    """A render whose parked samples would not fit the scratch cap is issued as several launches over consecutive
+    sample ranges (bt_api.cpp); BT_SCRATCH_CAP shrinks the cap so that 40 samples need 4 launches (12+12+12+4)."""
+    w, h, spp = 64, 48, 40
+    monkeypatch.setenv("BT_SCRATCH_CAP", str(64 * 48 * 16 * 12))
+    buf, stats, _ = gpu_render(bendy, "volume", w, h, spp)
+    it, seg = oracle_render(oracle, "volume", w, h, spp)
+    assert stats.slices > 1 and stats.segments == seg and stats.samples == w * h * spp
+    assert np.array_equal(buf.numpy(), it)
+
+
 def test_sliced_render_adds_to_prefilled_buffer(bendy, oracle):
     w, h = 48, 32
     sc, cam = gpu_scene(bendy, "scene", w, h)
