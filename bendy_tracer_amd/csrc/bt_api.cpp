@@ -316,7 +316,8 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         if (const char *e = getenv("BT_SCRATCH_CAP")) cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // bytes; tests
         auto pick = [&](uint64_t T) {
             uint32_t S = 1;
-            while (S < 16 && T / (2 * S) >= 16) S *= 2;             // >= 16 samples per slice
+            const uint64_t per_lane = P.lens_on ? 4 : 16;          // bent paths differ far more in length: balance earlier
+            while (S < 16 && T / (2 * S) >= per_lane) S *= 2;      // >= 16 samples per lane of the workgroup
             const uint64_t waves = (uint64_t)grid * 4;             // too few pixels to fill the GPU: go down to 4 per slice
             while (S < 16 && waves * S < 4 * 5120 && T / (2 * S) >= 4) S *= 2;
             return S;

@@ -8,18 +8,21 @@
 //   sphere.rs, rect.rs, cuboid.rs), material shading (material.rs) and the density-map
 //   march (volume.rs) -> `+=` into the RGBA32F accumulator (buffer.rs:159-178).
 //
-// Mapping to the hardware (DESIGN.md "Kernel"):
-//   * one lane owns one pixel and walks that pixel's samples in order, so the per-pixel
-//     float sum has the reference's order and needs no atomics;
-//   * a wave is an 8x8 pixel tile.  Every loop iteration is TRACE (one path segment, all lanes)
-//     followed by exactly ONE random event per lane -- a Diffuse / Metallic / Glass scatter, a
-//     volume step, or, for a lane whose path just ended, the camera ray of its next sample.
-//     The event's Philox block, its sin/cos, its basis construction and its final normalize
-//     are shared by all event kinds, so those instructions run with every lane active; a wave
-//     never idles on its longest path;
-//   * the primitive table is read with wave-uniform indices -> scalar (SMEM) loads that
-//     broadcast through SGPRs; per-lane lookups (hit primitive, material, light, density)
-//     go to tables staged in LDS;
+// Mapping to the hardware:
+//   * a workgroup owns a block of 256/S pixels (S = 1..16) and all of their samples in this launch.  For S > 1
+//     (the default for launches with >= 8 samples per pixel) the block's (pixel, sample) pairs are a work queue in
+//     LDS: a lane whose path has ended takes the next pair, every sample's value is parked in HBM and the last
+//     wave of the workgroup adds the parked values to the frame in sample order -- the reference's per-pixel
+//     summation order, no atomics on the frame.  For S = 1 a lane owns one pixel and sums in a register;
+//   * every loop iteration is TRACE (one path segment, all lanes) followed by exactly ONE random event per lane --
+//     a Diffuse / Metallic / Glass scatter, a volume step, or, for a lane whose path just ended, the camera ray of
+//     its next sample.  The event's Philox block, its sin/cos, its basis construction and its final normalize are
+//     shared by all event kinds, so those instructions run with every lane active; a wave never idles on its
+//     longest path;
+//   * the primitive table is read with wave-uniform indices through the constant address space -> scalar (SMEM)
+//     loads that broadcast through SGPRs; per-lane lookups (hit primitive, material, light, density) go to tables
+//     staged in LDS; the camera block of the launch parameters is read where it is used, not kept in SGPRs;
+//   * template flags select a build without rect code / without the volume march for scenes that have neither;
 //   * no MFMA: there is no dense contraction on this path.
 #include "bt_device.hpp"
 
