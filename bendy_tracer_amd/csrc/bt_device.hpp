@@ -251,11 +251,18 @@ struct HitRec {
 // object and the clip is [0, volume_step].
 // RECTS = false: the scene holds spheres only (bt_api.cpp checks), all rect code drops out of the build.
 // VOLS = false: no sphere carries a volume, so nothing ever marches and the hit_volumetric test drops out.
-template <bool RECTS = true, bool VOLS = true>
+// SHORT = true (the chords of the lens march): the segment is at most h.t long on entry, so a sphere whose surface
+// is farther than that from the origin in either direction cannot be touched -- a two-compare reject (with a 1e-4
+// relative safety margin against rounding) in front of the quadratic; it can only skip tests that would fail.
+template <bool RECTS = true, bool VOLS = true, bool SHORT = false>
 BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int last_object, HitRec &h) {
     BtPrimK &R = prims[i];                      // wave-uniform index -> scalar loads
     if (!RECTS || R.kind == BT_PRIM_SPHERE) {
         V3 c = mk(R.c);
+        if (SHORT) {
+            const float d2 = len2(o - c), outer = R.radius + h.t, inner = R.radius - h.t;
+            if (d2 > (outer * outer) * 1.0001f || (inner > 0.0f && d2 < (inner * inner) * 0.9999f)) return;
+        }
         bool taken = false;
         if (VOLS && R.object == last_object) {  // Sphere::hit_volumetric (sphere.rs:150-166)
             V3 e = (o + d * h.t) - c;
@@ -305,7 +312,7 @@ BT_DEV HitRec intersect_listed(const BtLaunch &P, V3 o, V3 d, float tmin, float 
     h.p_neg = false;
     BtPrimK *prims = prim_table(P);
     const __attribute__((address_space(4))) int32_t *rows = (const __attribute__((address_space(4))) int32_t *)P.lens_prims;
-    for (int j = 0; j < P.n_lens_prims; ++j) intersect_row<RECTS, false>(prims, rows[j], o, d, tmin, -1, h);
+    for (int j = 0; j < P.n_lens_prims; ++j) intersect_row<RECTS, false, true>(prims, rows[j], o, d, tmin, -1, h);
     return h;
 }
 
