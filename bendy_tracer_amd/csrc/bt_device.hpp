@@ -251,17 +251,19 @@ struct HitRec {
 // object and the clip is [0, volume_step].
 // RECTS = false: the scene holds spheres only (bt_api.cpp checks), all rect code drops out of the build.
 // VOLS = false: no sphere carries a volume, so nothing ever marches and the hit_volumetric test drops out.
-// SHORT = true (the chords of the lens march): the segment is at most h.t long on entry, so a sphere whose surface
-// is farther than that from the origin in either direction cannot be touched -- a two-compare reject (with a 1e-4
-// relative safety margin against rounding) in front of the quadratic; it can only skip tests that would fail.
-template <bool RECTS = true, bool VOLS = true, bool SHORT = false>
-BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int last_object, HitRec &h) {
+// short_seg (wave-uniform: the chords of the lens march; tried for waves in which every lane is on a volume-march step
+// too -- such waves are too rare to matter, profiles/r01e/ab_march_reject.log): the segment is at most h.t long on entry, so a sphere whose surface is farther than that from the origin in either
+// direction cannot be touched -- a two-compare reject (with a 1e-4 relative safety margin against rounding) in front
+// of the quadratic; it can only skip tests that would fail.  The marched sphere's hit_volumetric test is never skipped.
+template <bool RECTS = true, bool VOLS = true>
+BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int last_object, HitRec &h, bool short_seg) {
     BtPrimK &R = prims[i];                      // wave-uniform index -> scalar loads
     if (!RECTS || R.kind == BT_PRIM_SPHERE) {
         V3 c = mk(R.c);
-        if (SHORT) {
+        bool far = false;                       // short_seg is wave-uniform: the reject costs nothing elsewhere
+        if (short_seg) {
             const float d2 = len2(o - c), outer = R.radius + h.t, inner = R.radius - h.t;
-            if (d2 > (outer * outer) * 1.0001f || (inner > 0.0f && d2 < (inner * inner) * 0.9999f)) return;
+            far = d2 > (outer * outer) * 1.0001f || (inner > 0.0f && d2 < (inner * inner) * 0.9999f);
         }
         bool taken = false;
         if (VOLS && R.object == last_object) {  // Sphere::hit_volumetric (sphere.rs:150-166)
@@ -272,7 +274,7 @@ BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int las
                 taken = true;
             }
         }
-        if (!taken) {
+        if (!taken && !far) {
             float t;
             if (sphere_t(o, d, c, R.radius, tmin, h.t, t)) {
                 h.t = t;
@@ -291,7 +293,7 @@ BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int las
     }
 }
 template <bool RECTS = true, bool VOLS = true>
-BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object) {
+BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object, bool short_seg = false) {
     HitRec h;
     h.t = tmax;
     h.prim = -1;
@@ -299,7 +301,7 @@ BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, i
     h.p_neg = false;
     const int n = P.n_prims;
     BtPrimK *prims = prim_table(P);
-    for (int i = 0; i < n; ++i) intersect_row<RECTS, VOLS>(prims, i, o, d, tmin, last_object, h);
+    for (int i = 0; i < n; ++i) intersect_row<RECTS, VOLS>(prims, i, o, d, tmin, last_object, h, short_seg);
     return h;
 }
 // Lens extension: the same loop over the rows listed in P.lens_prims (ascending, so ties resolve as in intersect()).
@@ -312,7 +314,7 @@ BT_DEV HitRec intersect_listed(const BtLaunch &P, V3 o, V3 d, float tmin, float 
     h.p_neg = false;
     BtPrimK *prims = prim_table(P);
     const __attribute__((address_space(4))) int32_t *rows = (const __attribute__((address_space(4))) int32_t *)P.lens_prims;
-    for (int j = 0; j < P.n_lens_prims; ++j) intersect_row<RECTS, false, true>(prims, rows[j], o, d, tmin, -1, h);
+    for (int j = 0; j < P.n_lens_prims; ++j) intersect_row<RECTS, false>(prims, rows[j], o, d, tmin, -1, h, true);
     return h;
 }
 
