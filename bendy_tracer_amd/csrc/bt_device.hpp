@@ -410,6 +410,18 @@ BT_DEV BlockPixel block_pixel(uint32_t sub, uint32_t q, uint32_t pxb) {
     return r;
 }
 
+// The scatter probability of one march step, Volume::shade's `volume_step * density.sample(coord)` (volume.rs:26-35)
+// with coord = (pos - bbox.min) / bbox.size of the sphere's bounding box (sphere.rs:35-38).
+BT_DEV float march_density(const BtLaunch &P, const SceneLds &S, int vol_index, V3 prim_c, float prim_radius, V3 pos) {
+    const BtVolume &vol = S.volumes[vol_index];
+    const V3 hsz = mk(prim_radius, prim_radius, prim_radius);
+    const V3 bmin = prim_c - hsz, bmax = prim_c + hsz;                // sphere.rs:35-38
+    const V3 size = bmax - bmin;
+    const V3 rel = pos - bmin;
+    const V3 coord = mk(rel.x / size.x, rel.y / size.y, rel.z / size.z);
+    return P.volume_step * density_sample(vol, S.density, coord);
+}
+
 BT_DEV unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

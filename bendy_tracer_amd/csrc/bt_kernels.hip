@@ -435,13 +435,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                 dir = base + v * M.roughness;
             } else if (VOLS) {
                 // ---- Volume::shade (volume.rs:26-60) ----
-                const BtVolume &vol = S.volumes[vol_index];
-                const V3 hsz = mk(prim_radius, prim_radius, prim_radius);
-                const V3 bmin = prim_c - hsz, bmax = prim_c + hsz;        // sphere.rs:35-38
-                const V3 size = bmax - bmin;
-                const V3 rel = pos - bmin;
-                const V3 coord = mk(rel.x / size.x, rel.y / size.y, rel.z / size.z);
-                const float density = P.volume_step * density_sample(vol, S.density, coord);
+                const float density = march_density(P, S, vol_index, prim_c, prim_radius, pos);
                 if (density >= 1.0f || bernoulli(u.x, density)) {
                     if (inside) new_o = pos - (rd * P.volume_step) * u24(u.y);
                     dir = v;
