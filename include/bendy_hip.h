@@ -81,7 +81,8 @@ typedef struct {
     uint64_t pixels;
     float kernel_ms;           /* HIP-event time of the render kernel(s), 0 if not measured */
     uint64_t lens_steps;       /* RK4 steps taken by the lens extension (0 when it is off) */
-    uint32_t slices;           /* waves that shared a pixel's samples in the last launch (1 = lane owns all of them) */
+    uint32_t slices;           /* S of the last launch: workgroups own 256/S pixels and deal their samples to the lanes
+                                * through a queue (1 = a lane owns a pixel and all of its samples); DESIGN.md 5.3 */
     uint32_t reserved;
 } bt_stats;
 
@@ -177,8 +178,10 @@ int bt_preview_device(const float *rgba_device, uint8_t *rgba8_device, uint32_t 
 int bt_preview(const float *rgba_host, uint8_t *rgba8_host, uint32_t width, uint32_t height, uint32_t samples,
                int32_t color_space);
 
-/* Two bit-identical implementations of the render kernel exist (DESIGN.md "Kernel"):
- * BT_KERNEL_LANES  -- a lane owns a pixel, path state in registers (default, fastest measured);
+/* Two bit-identical implementations of the render kernel exist:
+ * BT_KERNEL_LANES  -- path state in registers; a workgroup owns a block of pixels and deals their samples to its lanes
+ *                     through an LDS work queue, or a lane owns a pixel for very shallow launches (default, fastest
+ *                     measured);
  * BT_KERNEL_SORTED -- path state in LDS, the workgroup re-sorts its 256 paths by pending event kind
  *                     every iteration (ballot / prefix-sum compaction).  Process-wide switch for A/B
  *                     measurements; BT_KERNEL_DEFAULT restores the built-in choice. */
