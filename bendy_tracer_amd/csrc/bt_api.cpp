@@ -74,6 +74,7 @@ struct bt_scene {
     DeviceArray<BtVolume> d_volumes;
     DeviceArray<BtLight> d_lights;
     DeviceArray<BtLightFace> d_light_faces;
+    DeviceArray<BtSpherePair> d_sphere_pairs;
     DeviceArray<float> d_density;
     DeviceArray<int32_t> d_lens_prims;     // lens extension: rows of d_prims near the sphere of influence
     bt_lens lens_prims_for{};              // the lens d_lens_prims was built for
@@ -127,6 +128,21 @@ int ensure_device(bt_scene *s) {
     BT_HIP(s->d_volumes.upload(s->flat.volumes));
     BT_HIP(s->d_lights.upload(s->flat.lights));
     BT_HIP(s->d_light_faces.upload(s->flat.light_faces));
+    {
+        std::vector<BtSpherePair> pairs;
+        const std::vector<BtPrim> &pr = s->flat.prims;
+        bool spheres_only = true;
+        for (const BtPrim &R : pr) spheres_only = spheres_only && (R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_SPHERE;
+        if (spheres_only)
+            for (size_t i = 0; i < pr.size(); i += 2) {
+                const BtPrim &A = pr[i], &B = pr[i + 1 < pr.size() ? i + 1 : i];
+                BtSpherePair q{};
+                q.cx[0] = A.c.x; q.cy[0] = A.c.y; q.cz[0] = A.c.z; q.radius[0] = A.radius; q.object[0] = A.object;
+                q.cx[1] = B.c.x; q.cy[1] = B.c.y; q.cz[1] = B.c.z; q.radius[1] = B.radius; q.object[1] = B.object;
+                pairs.push_back(q);
+            }
+        BT_HIP(s->d_sphere_pairs.upload(pairs));
+    }
     BT_HIP(s->d_density.upload(s->flat.density));
     if (!s->d_counters) BT_HIP(hipMalloc((void **)&s->d_counters, BT_N_COUNTERS * sizeof(unsigned long long)));
     if (!s->ev_start) BT_HIP(hipEventCreate(&s->ev_start));
@@ -198,6 +214,7 @@ int fill_launch(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt
     P.volumes = s->d_volumes.ptr;
     P.lights = s->d_lights.ptr;
     P.light_faces = s->d_light_faces.ptr;
+    P.sphere_pairs = s->d_sphere_pairs.count ? s->d_sphere_pairs.ptr : nullptr;
     P.density = s->d_density.ptr;
     P.n_prims = (int32_t)f.prims.size();
     P.n_materials = (int32_t)f.materials.size();

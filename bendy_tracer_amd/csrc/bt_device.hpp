@@ -292,8 +292,66 @@ BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int las
         }
     }
 }
+// Sphere-only scenes: try_hit / try_hit_volume over BtSpherePair rows.  The clip-independent half of Sphere::hit
+// (oc, half_b = dot(oc, d), c = |oc|^2 - r^2, discriminant; sphere.rs:122-127) is formed for two spheres at once in
+// float2 lanes (v_pk_add_f32 / v_pk_mul_f32, the pair's constants straight from SGPR pairs) -- the same IEEE
+// operations in the same order per sphere as sphere_t() -- then each sphere's root selection runs against the running
+// clip, first sphere first, exactly as the one-at-a-time loop does.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <bool VOLS>
+BT_DEV HitRec intersect_spheres(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object) {
+    HitRec h;
+    h.t = tmax;
+    h.prim = -1;
+    h.inside = false;
+    h.p_neg = false;
+    const int n = P.n_prims;
+    typedef const __attribute__((address_space(4))) BtSpherePair PairK;
+    PairK *pairs = (PairK *)P.sphere_pairs;
+    for (int i = 0; i < n; i += 2) {
+        PairK &Q = pairs[i >> 1];               // wave-uniform index -> scalar loads
+        const f2 cx = {Q.cx[0], Q.cx[1]}, cy = {Q.cy[0], Q.cy[1]}, cz = {Q.cz[0], Q.cz[1]}, r = {Q.radius[0], Q.radius[1]};
+        const f2 ocx = (f2)(o.x) - cx, ocy = (f2)(o.y) - cy, ocz = (f2)(o.z) - cz;
+        const f2 half_b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+        const f2 cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r * r;
+        const f2 disc = half_b * half_b - cc;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 1 && i + 1 >= n) break;
+            const int row = i + s;
+            const float rs = s ? r.y : r.x;
+            bool taken = false;
+            if (VOLS && (s ? Q.object[1] : Q.object[0]) == last_object) {   // Sphere::hit_volumetric (sphere.rs:150-166)
+                const V3 e = (o + d * h.t) - mk(s ? cx.y : cx.x, s ? cy.y : cy.x, s ? cz.y : cz.x);
+                if (len2(e) <= rs * rs) {
+                    h.prim = row;
+                    h.inside = true;
+                    taken = true;
+                }
+            }
+            const float ds = s ? disc.y : disc.x, hb = s ? half_b.y : half_b.x;
+            if (!taken && ds >= 0.0f) {                                      // sphere_t()'s root selection
+                const float sqrtd = sqrtf(ds);
+                float t = -hb - sqrtd;
+                bool ok = !(t < tmin || t > h.t);
+                if (!ok) {
+                    t = -hb + sqrtd;
+                    ok = !(t < tmin || t > h.t);
+                }
+                if (ok) {
+                    h.t = t;
+                    h.prim = row;
+                    h.inside = false;
+                }
+            }
+        }
+    }
+    return h;
+}
+
 template <bool RECTS = true, bool VOLS = true>
 BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object, bool short_seg = false) {
+    if (!RECTS && !short_seg) return intersect_spheres<VOLS>(P, o, d, tmin, tmax, last_object);
     HitRec h;
     h.t = tmax;
     h.prim = -1;

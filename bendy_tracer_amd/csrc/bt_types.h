@@ -43,6 +43,17 @@ struct BtPrim {
 };
 static_assert(sizeof(BtPrim) == 144, "BtPrim must be 144 bytes");
 
+// Sphere-only scenes: the same centres / radii again, two spheres side by side, so that the part of Sphere::hit that
+// does not depend on the running clip (oc, half_b, c, discriminant -- sphere.rs:122-127) is evaluated for two
+// spheres at once with packed FP32 instructions (bt_device.hpp intersect_spheres).  Row p = primitives 2p, 2p + 1;
+// an odd tail repeats the last sphere in slot 1 (never tested).
+struct BtSpherePair {
+    float cx[2], cy[2], cz[2], radius[2];
+    int32_t object[2];
+    int32_t pad[2];
+};
+static_assert(sizeof(BtSpherePair) == 48, "BtSpherePair must be 48 bytes");
+
 // Per-lane (divergent) lookups after the loop read this 32-byte digest from LDS.
 struct BtPrimLite {
     BtV3 c;             // sphere centre | rect world normal
@@ -94,6 +105,7 @@ struct BtLight {
 struct BtLaunch {
     // scene tables
     const BtPrim *prims;
+    const BtSpherePair *sphere_pairs; // sphere-only scenes (any_rects == 0), else null
     const BtMaterial *materials;
     const BtVolume *volumes;
     const BtLight *lights;
