@@ -344,12 +344,17 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) S = (uint32_t)v;
         }
-        if (S > 1) {
+        // the work-queue kernel whenever a pixel gets more than one sample in this launch (also with whole tiles, S = 1:
+        // the reference's interactive pattern, 1 sample x Subpixel(2) per call, gains 2-18 % from the balancing alone,
+        // profiles/r01e/time_progressive.log); the lanes kernel for one ray per pixel
+        bool queue = (uint64_t)chunk * nn >= 2;
+        if (const char *e = getenv("BT_QUEUE")) queue = atoi(e) != 0;   // A/B knob: the queue with whole tiles (S = 1)
+        if (queue) {
             const uint64_t per_sample = px_launch * nn * 4 * sizeof(float);
             if (per_sample * chunk > cap) chunk = (uint32_t)std::max<uint64_t>(1, cap / per_sample);
             if (chunk < (uint32_t)P.samples && !getenv("BT_SLICES")) S = pick((uint64_t)chunk * nn);
         }
-        if (S > 1) {
+        if (queue) {
             const uint64_t need = px_launch * nn * chunk * 4 * sizeof(float);
             if (s->scratch_bytes < need) {
                 if (s->d_scratch) (void)hipFree(s->d_scratch);
@@ -360,11 +365,11 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
                 } else {
                     (void)hipGetLastError();              // no room for the scratch: the lanes kernel needs none
                     s->d_scratch = nullptr;
-                    S = 1;
+                    queue = false;
                 }
             }
         }
-        if (S > 1) {
+        if (queue) {
             P.slices = (int32_t)S;
             P.scratch = s->d_scratch;
         } else {
@@ -389,6 +394,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     const bool use_sorted = can_sort && variant == BT_KERNEL_SORTED && !P.lens_on;   // the lens lives in the lanes kernel
     if (use_sorted) {                             // the regrouping kernel owns whole pixels
         P.slices = 1;
+        P.scratch = nullptr;
         BT_HIP(bt_launch_render_sorted(&P, output, grid, s->flat.lds_bytes(), stream));
     } else {
         const uint32_t all = (uint32_t)P.samples, base = P.sample_base;

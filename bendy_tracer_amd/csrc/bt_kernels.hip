@@ -638,7 +638,7 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
                                        hipStream_t stream) {
     // grid = tiles to render; with sample slicing a tile is S workgroups (see the mapping in the kernel)
     dim3 g(grid * (unsigned)P->slices), b(256);
-    const bool sliced = P->slices > 1;
+    const bool sliced = P->scratch != nullptr;      // the work-queue instantiation (any S, also whole tiles)
     // scene classes: bit 0 = some sphere carries a volume (volume.json, cloud.json), bit 1 = rects / cuboids present
     // (the Cornell boxes); scene.json is class 0
     const int cls = (P->any_rects ? 2 : 0) | (P->any_volumes ? 1 : 0);
