@@ -1,5 +1,6 @@
 #!/bin/bash
-# Developer tool: section shares of wave cycles (libbendy_hip_profile.so = the -DBT_PROFILE build) on the BASELINE workloads.
+# Developer tool: section shares of wave cycles on the BASELINE workloads.  Needs the -DBT_PROFILE build:
+#   make -C bendy_tracer_amd/csrc profile     (here, before gpurun; the .so travels with the snapshot)
 cd $GRAFT_REPO_ROOT
 cp bendy_tracer_amd/libbendy_hip.so /tmp/base.so
 cp bendy_tracer_amd/libbendy_hip_profile.so bendy_tracer_amd/libbendy_hip.so
