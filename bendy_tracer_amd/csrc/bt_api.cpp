@@ -334,15 +334,15 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         auto pick = [&](uint64_t T) {
             uint32_t S = 1;
             const uint64_t per_lane = P.lens_on ? 4 : 16;          // bent paths differ far more in length: balance earlier
-            while (S < 16 && T / (2 * S) >= per_lane) S *= 2;      // >= 16 samples per lane of the workgroup
+            while (S < 32 && T / (2 * S) >= per_lane) S *= 2;      // >= 16 samples per lane of the workgroup
             const uint64_t waves = (uint64_t)grid * 4;             // too few pixels to fill the GPU: go down to 4 per slice
             while (S < 16 && waves * S < 4 * 5120 && T / (2 * S) >= 4) S *= 2;
             return S;
         };
         uint32_t S = pick((uint64_t)chunk * nn);
-        if (const char *e = getenv("BT_SLICES")) {                 // A/B knob: 1, 2, 4, 8, 16
+        if (const char *e = getenv("BT_SLICES")) {                 // A/B knob: 1, 2, 4, 8, 16, 32
             const int v = atoi(e);
-            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) S = (uint32_t)v;
+            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) S = (uint32_t)v;
         }
         // the work-queue kernel whenever a pixel gets more than one sample in this launch (also with whole tiles, S = 1:
         // the reference's interactive pattern, 1 sample x Subpixel(2) per call, gains 2-18 % from the balancing alone,

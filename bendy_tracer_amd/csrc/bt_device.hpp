@@ -451,7 +451,7 @@ BT_DEV float density_sample(const BtVolume &vol, const float *density, V3 coord)
 }
 
 // Pixel q of block `sub` of a 16x16 tile that is cut into 256 / pxb blocks (bt_render_kernel's mapping): blocks of
-// 256, 128 or 64 pixels are made of whole 8x8 quadrants, smaller ones are 8x4 (pxb 32) or 4x4 (pxb 16) pixels,
+// 256, 128 or 64 pixels are made of whole 8x8 quadrants, smaller ones are 8x4 (pxb 32), 4x4 (pxb 16) or 4x2 (pxb 8) pixels,
 // numbered row-major inside the tile.
 struct BlockPixel { uint32_t x, y; };
 BT_DEV BlockPixel block_pixel(uint32_t sub, uint32_t q, uint32_t pxb) {
@@ -461,9 +461,9 @@ BT_DEV BlockPixel block_pixel(uint32_t sub, uint32_t q, uint32_t pxb) {
         r.x = ((quad & 1) << 3) | (q & 7);
         r.y = ((quad >> 1) << 3) | ((q & 63) >> 3);
     } else {
-        const uint32_t bw = pxb >= 32 ? 8u : 4u, nbx = 16u / bw;
+        const uint32_t bw = pxb >= 32 ? 8u : 4u, bh = pxb / bw, nbx = 16u / bw;      // 8x4, 4x4, 4x2
         r.x = (sub % nbx) * bw + q % bw;
-        r.y = (sub / nbx) * 4u + q / bw;
+        r.y = (sub / nbx) * bh + q / bw;
     }
     return r;
 }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
     // ---- tile / pixel mapping ----
     // !SLICED: a workgroup is one 16x16 tile, wave w = its 8x8 quadrant w, a lane owns one pixel and walks that
     // pixel's samples in order (the per-pixel sum lives in `acc`).
-    // SLICED (BtLaunch::slices = NS in {2,4,8,16}): the tile is cut into NS blocks of pxb = 256/NS pixels and a
+    // SLICED (BtLaunch::slices = NS in {1,2,4,8,16,32}): the tile is cut into NS blocks of pxb = 256/NS pixels and a
     // workgroup owns one block: its pxb * T (pixel, sample) pairs are work items i = k * pxb + pixel, handed out
     // through an LDS counter (one atomic per wave and iteration, see the loop) -- a lane whose path has ended takes
     // the next item, so all 256 lanes stay busy until the block's samples run out, and 64 consecutive items are the
@@ -520,29 +520,63 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
         arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
         if (arrived == (blockDim.x >> 6) - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (uint32_t q = lane; q < pxb; q += 64) {
+            if (pxb >= 64) {
+                for (uint32_t q = lane; q < pxb; q += 64) {
+                    const BlockPixel b2 = block_pixel(sub, q, pxb);
+                    const uint32_t qx = tx * BT_TILE_DIM + b2.x, qy = ty * BT_TILE_DIM + b2.y;
+                    if (!((ty < P.tiles_y) && (qx < P.width) && (qy < P.height))) continue;
+                    float *o = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + b2.y * BT_TILE_DIM + b2.x) * 4
+                                         : P.out + ((size_t)qy * P.width + qx) * 4;
+                    const float4 *src = (const float4 *)P.scratch + (size_t)bi * T * pxb + q;
+                    V3 sum = mk(o[0], o[1], o[2]);
+                    uint32_t kk = 0;
+                    for (; kk + 8 <= T; kk += 8) {             // eight loads in flight, additions strictly in order
+                        float4 v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j) * pxb];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
+                    }
+                    for (; kk < T; ++kk) {
+                        const float4 v = src[(size_t)kk * pxb];
+                        sum = sum + mk(v.x, v.y, v.z);
+                    }
+                    o[0] = sum.x;
+                    o[1] = sum.y;
+                    o[2] = sum.z;
+                }
+            } else {
+                // 32, 16 or 8 pixels (deep launches, T in the hundreds): J = 64 / pxb lanes per pixel fetch interleaved
+                // samples (8 J in flight per pixel), lane (q, 0) adds them in sample order out of the others' registers
+                const uint32_t J = 64u / pxb, q = lane % pxb, jl = lane / pxb;
                 const BlockPixel b2 = block_pixel(sub, q, pxb);
                 const uint32_t qx = tx * BT_TILE_DIM + b2.x, qy = ty * BT_TILE_DIM + b2.y;
-                if (!((ty < P.tiles_y) && (qx < P.width) && (qy < P.height))) continue;
+                const bool owner = jl == 0 && (ty < P.tiles_y) && (qx < P.width) && (qy < P.height);
                 float *o = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + b2.y * BT_TILE_DIM + b2.x) * 4
                                      : P.out + ((size_t)qy * P.width + qx) * 4;
                 const float4 *src = (const float4 *)P.scratch + (size_t)bi * T * pxb + q;
-                V3 sum = mk(o[0], o[1], o[2]);
-                uint32_t kk = 0;
-                for (; kk + 8 <= T; kk += 8) {             // eight loads in flight, additions strictly in order
+                V3 sum = mk(0.0f, 0.0f, 0.0f);
+                if (owner) sum = mk(o[0], o[1], o[2]);
+                for (uint32_t kk = 0; kk < T; kk += 8 * J) {
                     float4 v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j) * pxb];
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t k2 = kk + (uint32_t)u * J + jl;
+                        v[u] = k2 < T ? src[(size_t)k2 * pxb] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
+                    for (int u = 0; u < 8; ++u)
+                        for (uint32_t jj = 0; jj < J; ++jj) {
+                            const int from = (int)(q + jj * pxb);
+                            const V3 val = mk(__shfl(v[u].x, from, 64), __shfl(v[u].y, from, 64), __shfl(v[u].z, from, 64));
+                            if (kk + (uint32_t)u * J + jj < T) sum = sum + val;
+                        }
                 }
-                for (; kk < T; ++kk) {
-                    const float4 v = src[(size_t)kk * pxb];
-                    sum = sum + mk(v.x, v.y, v.z);
+                if (owner) {
+                    o[0] = sum.x;
+                    o[1] = sum.y;
+                    o[2] = sum.z;
                 }
-                o[0] = sum.x;
-                o[1] = sum.y;
-                o[2] = sum.z;
             }
         }
     }

@@ -243,9 +243,9 @@ def test_sliced_render_matches_oracle(bendy, oracle, name, w, h, spp, n, output)
     assert np.array_equal(buf.numpy(), it)
 
 
-@pytest.mark.parametrize("slices", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("slices", [1, 2, 4, 8, 16, 32])
 def test_every_slice_count_gives_the_same_frame(bendy, oracle, monkeypatch, slices):
-    """BT_SLICES forces S (developer knob): each block shape (16x16 ... 4x4 pixels) must give the oracle's bits,
+    """BT_SLICES forces S (developer knob): each block shape (16x16 ... 4x2 pixels) must give the oracle's bits,
     on a ragged frame, in the full-frame and in the sharded layout."""
     import torch
     monkeypatch.setenv("BT_SLICES", str(slices))
