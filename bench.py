@@ -289,7 +289,9 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(args.workload) if world == 1 else None,
-            "kernel": "bt_render_kernel<0, false, %s>" % ("true" if scene.last_stats().slices > 1 else "false"),
+            # template arguments <OUTPUT, LENS, SLICED (work queue), RECTS, VOLS>, as rocprofv3 prints them
+            "kernel": "bt_render_kernel<0, false, %s, %s, %s>" % (
+                "true" if spp >= 2 else "false", *{"scene": ("false", "false"), "volume": ("false", "true")}.get(scene_name, ("true", "false"))),
             "kernel_ms": round(k_ms, 4), "slices": scene.last_stats().slices,
             "render_stream_ms_per_step_timed_region": round(statistics.mean(step_ms), 4),
             "segments_per_launch": int(seg), "segments_per_sample": round(seg / (my_pixels * spp), 4),
