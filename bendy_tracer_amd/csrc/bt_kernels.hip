@@ -676,7 +676,15 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
     // scene classes: bit 0 = some sphere carries a volume (volume.json, cloud.json), bit 1 = rects / cuboids present
     // (the Cornell boxes); scene.json is class 0
     const int cls = (P->any_rects ? 2 : 0) | (P->any_volumes ? 1 : 0);
-#define BT_LAUNCH(O, L, S, R, V) hipLaunchKernelGGL((bt_render_kernel<O, L, S, R, V>), g, b, lds_bytes, stream, *P)
+    // scene tables beyond the default 64 KB of dynamic LDS (hundreds of objects): gfx950 has 160 KB per CU, the limit
+    // has to be raised per kernel; one workgroup per CU is then all that fits
+#define BT_LAUNCH(O, L, S, R, V)                                                                                 \
+    do {                                                                                                         \
+        if (lds_bytes > 48 * 1024)                                                                               \
+            (void)hipFuncSetAttribute((const void *)bt_render_kernel<O, L, S, R, V>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
+        hipLaunchKernelGGL((bt_render_kernel<O, L, S, R, V>), g, b, lds_bytes, stream, *P);                      \
+    } while (0)
 #define BT_LAUNCH_OUT(L, S, R, V)                                                                                \
     switch (output) {                                                                                            \
     case 0: BT_LAUNCH(0, L, S, R, V); break;                                                                     \

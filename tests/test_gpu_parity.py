@@ -462,6 +462,14 @@ def test_sorted_kernel_full_size_equals_default(bendy, sorted_kernel):
     assert sc_.segments == sd.segments and np.array_equal(c.numpy(), d.numpy())
 
 
+def test_scene_tables_beyond_64kb_of_lds(bendy, oracle):
+    """700 objects (~2000 table rows, ~100 KB of per-lane lookup tables): the launch raises the kernel's dynamic
+    LDS limit (gfx950: 160 KB per CU) instead of failing at the default 64 KB."""
+    from scene_gen import random_scene
+    gs = _compare_json_scene(bendy, oracle, random_scene(11, n_objects=700, n_lights=(3, 3)), 48, 32, 2)
+    assert gs.export_prims().shape[0] > 1800          # x 32 B of BtPrimLite alone is > 57 KB
+
+
 def test_many_objects(bendy, oracle):
     from scene_gen import random_scene
     gs = _compare_json_scene(bendy, oracle, random_scene(7, n_objects=60, n_lights=(4, 4)), 64, 40, 2)
