@@ -88,10 +88,11 @@ def load_pmc_traffic(workload):
         return None
 
 
-def lens_extension_rate(b, torch, scene_name, w, h, spp=16, steps=3):
+def lens_extension_rate(b, torch, scene_name, w, h, spp=64, steps=2):
     """Throughput of the same frame with the gravitational-lens EXTENSION switched on.  Not part of `value`:
     the reference has no lens code, so this mode has no reference behaviour and no parity claim
-    beyond GPU == this repo's CPU oracle; BASELINE.json's config text mentions geodesic stepping, hence the number."""
+    beyond GPU == this repo's CPU oracle; BASELINE.json's configs[2] reads "scene.json.gz 1920x1080 64spp with
+    gravitational-lens geodesic stepping", hence this number on exactly that frame and sample count."""
     lens = dict(centre=(0.6, 0.4, 4.0), rs=0.15, step=0.1, radius=6.0, max_steps=800)
     sc = b.Scene.load(os.path.join(ROOT, "scenes", f"{scene_name}.json.gz"))
     cam = sc.find_by_tag("camera")
