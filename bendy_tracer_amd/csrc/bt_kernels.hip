@@ -155,6 +155,11 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
     int bounce = 0, vbounce = 0, last_object = -1;
     uint32_t event = 0;
     bool pending = true;               // the lane has no ray yet: its next event is the camera ray
+    // phase voting (BtLaunch::phase_vote): a lane whose scatter event lost the vote keeps its hit for the next iteration
+    constexpr bool VOTE = !RECTS && !LENS;    // pays where the events, not TRACE, are most of an iteration
+    bool held = false;
+    float held_t = 0.0f;
+    int held_info = 0, waited = 0;     // held_info = prim | inside << 29 | p_neg << 30
     unsigned long long segments = 0, lens_steps = 0;
     LensState lens;                    // lens extension: the bent segment in progress (LENS builds only)
     bool bent = false;
@@ -214,6 +219,11 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                 bent = false;
                 captured = r < 0;
                 travelled = lens.travelled;
+            } else if (VOTE && held) {                // the hit found one iteration ago (phase voting)
+                h.t = held_t;
+                h.prim = held_info & 0x1fffffff;
+                h.inside = (held_info >> 29) & 1;
+                h.p_neg = (held_info >> 30) & 1;
             } else {
                 segments += 1;
                 h = intersect<RECTS, VOLS>(P, ro, rd, tmin, tmax, last_object);
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                     // sample_surface (mod.rs:454-486): emitted, then Material::shade
                     mat_index = pl.material;
                     const BtMaterial &M = S.materials[mat_index];
-                    L = L + beta * mk(M.emitted);
+                    if (!(VOTE && held)) L = L + beta * mk(M.emitted);
                     if (M.kind == BT_MAT_DIFFUSE) ev = EV_DIFFUSE;
                     else if (M.kind == BT_MAT_METALLIC) ev = EV_METALLIC;
                     else if (M.kind == BT_MAT_GLASS) ev = EV_GLASS;
@@ -275,8 +285,30 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
                 }
             }
             if (ended) finish_sample();
+            if (VOTE && P.phase_vote && ev != EV_GEN) {       // in case this lane's event loses the vote below
+                held_t = h.t;
+                held_info = h.prim | ((int)h.inside << 29) | ((int)h.p_neg << 30);
+            }
         }
         pending = false;
+
+        if (VOTE && P.phase_vote) {
+            // ---- camera event or scatter events this iteration?  The kind more lanes want; nobody waits more than
+            // P.phase_vote iterations.
+            const bool want_gen = ev == EV_GEN;
+            const unsigned long long m_gen = __ballot(want_gen), m_sc = __ballot(!want_gen);
+            bool gen_phase = __popcll(m_gen) >= __popcll(m_sc);
+            if (__ballot(!want_gen && waited >= P.phase_vote)) gen_phase = false;
+            else if (__ballot(want_gen && waited >= P.phase_vote)) gen_phase = true;
+            if (want_gen != gen_phase) {
+                waited += 1;
+                pending = want_gen;                   // no ray yet | the hit stays in held_t / held_info
+                held = !want_gen;
+                continue;
+            }
+            waited = 0;
+            held = false;
+        }
 
         // ---- a lane whose path has ended (or that has none yet) moves on to its next sample ----
         if (!SLICED) {

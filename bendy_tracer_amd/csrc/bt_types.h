@@ -145,6 +145,11 @@ struct BtLaunch {
     // finish adds them to the frame in sample order -- same additions, same order, same bits as slices = 1.
     int32_t slices;                   // 1 = a lane owns all samples of its pixel (no scratch)
     float *scratch;
+    // Phase voting (bt_kernels.hip, sphere-only builds): every iteration the wave runs EITHER the camera event OR the
+    // scatter / volume events, whichever more of its lanes want; the others keep what they have (no ray yet, or their
+    // hit) for the next iteration, at most phase_vote iterations in a row (0 = off).  Scheduling only: every lane
+    // performs the same operations in the same order.
+    int32_t phase_vote;
     // lens EXTENSION (not in the reference, default off; include/bendy_hip.h bt_lens)
     int32_t lens_on;
     BtV3 lens_c;
