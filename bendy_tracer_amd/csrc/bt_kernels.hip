@@ -294,12 +294,14 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
 
         if (VOTE && P.phase_vote) {
             // ---- camera event or scatter events this iteration?  The kind more lanes want; nobody waits more than
-            // P.phase_vote iterations.
+            // max_wait iterations.
+            // (a third phase for the volume steps alone was tried and lost, profiles/r01f/ab_phase_vote.log)
             const bool want_gen = ev == EV_GEN;
             const unsigned long long m_gen = __ballot(want_gen), m_sc = __ballot(!want_gen);
             bool gen_phase = __popcll(m_gen) >= __popcll(m_sc);
-            if (__ballot(!want_gen && waited >= P.phase_vote)) gen_phase = false;
-            else if (__ballot(want_gen && waited >= P.phase_vote)) gen_phase = true;
+            const unsigned long long starving = __ballot(waited >= P.phase_vote);
+            if (starving & m_sc) gen_phase = false;
+            else if (starving & m_gen) gen_phase = true;
             if (want_gen != gen_phase) {
                 waited += 1;
                 pending = want_gen;                   // no ray yet | the hit stays in held_t / held_info
