@@ -179,11 +179,18 @@ std::vector<int32_t> lens_candidates(const std::vector<BtPrim> &prims, const bt_
                         m[r][c] = (a[r1][c1] * a[r2][c2] - a[r1][c2] * a[r2][c1]) / det;
                     }
                 const double hw = std::sqrt((double)R.w_sqr), hh = std::sqrt((double)R.h_sqr);
+                // local axes: Rect.x / Rect.y, which BT_PRIM_RECT_LA rows replace by rows of the inverse (bt_types.h)
+                double lx[3] = {R.ax.x, R.ax.y, R.ax.z}, ly[3] = {R.ay.x, R.ay.y, R.ay.z};
+                if ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_RECT_LA)
+                    for (int i = 0; i < 3; ++i) {
+                        lx[i] = i == R.aa_u ? 1.0 : 0.0;
+                        ly[i] = i == R.aa_v ? 1.0 : 0.0;
+                    }
                 double bound = 0.0;
                 for (int sx = -1; sx <= 1; sx += 2)
                     for (int sy = -1; sy <= 1; sy += 2) {
-                        const double l[3] = {sx * hw * R.ax.x + sy * hh * R.ay.x, sx * hw * R.ax.y + sy * hh * R.ay.y,
-                                             sx * hw * R.ax.z + sy * hh * R.ay.z};
+                        const double l[3] = {sx * hw * lx[0] + sy * hh * ly[0], sx * hw * lx[1] + sy * hh * ly[1],
+                                             sx * hw * lx[2] + sy * hh * ly[2]};
                         double wv[3];
                         for (int r = 0; r < 3; ++r) wv[r] = m[r][0] * l[0] + m[r][1] * l[1] + m[r][2] * l[2];
                         bound = std::max(bound, std::sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]));

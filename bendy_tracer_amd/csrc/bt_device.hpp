@@ -226,6 +226,13 @@ BT_DEV bool rect_t(V3 o, V3 d, PrimRef &R, float tmin, float tmax, bool strict, 
         float lu = (u == 0 ? pos.x : (u == 1 ? pos.y : pos.z)) + (u == 0 ? R.it.x : (u == 1 ? R.it.y : R.it.z));
         float lv = (v == 0 ? pos.x : (v == 1 ? pos.y : pos.z)) + (v == 0 ? R.it.x : (v == 1 ? R.it.y : R.it.z));
         if (!(lu * lu <= R.w_sqr && lv * lv <= R.h_sqr)) return false;
+    } else if ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_RECT_LA) {
+        // Rect.x = +-e_u, Rect.y = +-e_v in LOCAL space: the projections' squared lengths are local[u]^2, local[v]^2
+        // (as above), so only those two components of `M^-1 * pos + t'` are formed -- component by component the
+        // expression of xf_vector() + it; the host has put the two rows where Rect.x / Rect.y sit in other rows.
+        const float lu = ((R.ax.x * pos.x + R.ax.y * pos.y) + R.ax.z * pos.z) + R.ax_w;     // rows u, v of M^-1 | t'
+        const float lv = ((R.ay.x * pos.x + R.ay.y * pos.y) + R.ay.z * pos.z) + R.ay_w;
+        if (!(lu * lu <= R.w_sqr && lv * lv <= R.h_sqr)) return false;
     } else {
         V3 local = xf_vector(mk(R.icx), mk(R.icy), mk(R.icz), pos) + mk(R.it);
         V3 ax = mk(R.ax), ay = mk(R.ay);

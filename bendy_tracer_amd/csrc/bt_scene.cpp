@@ -340,6 +340,14 @@ FlatScene flatten_scene(const Scene &sc) {
                               tf.cy.y == 1.0f && tf.cy.z == 0.0f && tf.cz.x == 0.0f && tf.cz.y == 0.0f && tf.cz.z == 1.0f;
         const int au = unit_axis(r.x), av = unit_axis(r.y);
         int shape = BT_PRIM_RECT;
+        if (au >= 0 && av >= 0 && au != av && !identity) {
+            shape = BT_PRIM_RECT_LA;
+            p.aa_u = au;
+            p.aa_v = av;
+            auto comp = [](BtV3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); };
+            p.ax = v3(comp(inv.cx, au), comp(inv.cy, au), comp(inv.cz, au)); p.ax_w = comp(inv.t, au);
+            p.ay = v3(comp(inv.cx, av), comp(inv.cy, av), comp(inv.cz, av)); p.ay_w = comp(inv.t, av);
+        }
         if (identity && au >= 0 && av >= 0) {
             shape = BT_PRIM_RECT_AA;
             p.aa_u = au;

@@ -22,8 +22,12 @@ struct BtV3 { float x, y, z; };
 // and two squares (DESIGN.md "Kernel").  BT_PRIM_RECT_AAN is such a rect whose world normal `c` is a signed unit
 // basis vector as well (component aa_w): then dot(d, n) = +-d[w] and dot(t - o, n) = +-(t[w] - o[w]) exactly, and
 // p / q = (t[w] - o[w]) / d[w] bit for bit -- the two dot products of rect.rs:120-124 reduce to one subtraction.
+// BT_PRIM_RECT_LA is a rect under any transform whose LOCAL axes Rect.x / Rect.y are signed unit basis vectors (every
+// cuboid face, cuboid.rs:19-30; the rotated box of the Cornell scenes): `local.project_onto_normalized(x)` then has
+// the squared length local[aa_u]^2 exactly, so only two components of `M^-1 * pos + t'` are formed and the two
+// projections (rect.rs:74-80) reduce to two squares.
 // BT_PRIM_STRICT marks cuboid faces (`manifold.t < t`, cuboid.rs:96).
-enum { BT_PRIM_SPHERE = 0, BT_PRIM_RECT = 1, BT_PRIM_RECT_AA = 2, BT_PRIM_RECT_AAN = 3, BT_PRIM_SHAPE_MASK = 3, BT_PRIM_STRICT = 4 };
+enum { BT_PRIM_SPHERE = 0, BT_PRIM_RECT = 1, BT_PRIM_RECT_AA = 2, BT_PRIM_RECT_AAN = 3, BT_PRIM_RECT_LA = 4, BT_PRIM_SHAPE_MASK = 7, BT_PRIM_STRICT = 8 };
 struct BtPrim {
     int32_t kind;
     int32_t object;     // object index (ascending ObjectRef) -- `last_object` test, mod.rs:415
@@ -38,8 +42,10 @@ struct BtPrim {
     BtV3 icy; int32_t aa_u;     // BT_PRIM_RECT_AA: component index of Rect.x
     BtV3 icz; int32_t aa_v;     // BT_PRIM_RECT_AA: component index of Rect.y
     BtV3 it;  int32_t aa_w;     // BT_PRIM_RECT_AAN: component index of the normal
-    BtV3 ax;  float pad3;    // Rect.x (rect.rs:17)
-    BtV3 ay;  float pad4;    // Rect.y (rect.rs:18)
+    // Rect.x, Rect.y (rect.rs:17-18); for BT_PRIM_RECT_LA rows instead the two rows of `M^-1 | t'` that the test
+    // needs: (ax, ax_w) = (icx[u], icy[u], icz[u], it[u]), (ay, ay_w) likewise for v
+    BtV3 ax;  float ax_w;
+    BtV3 ay;  float ay_w;
 };
 static_assert(sizeof(BtPrim) == 144, "BtPrim must be 144 bytes");
 

@@ -68,15 +68,17 @@ def _expected_prims(o, sc):
         o.lib().bto_affine_inverse(C.byref(tf), C.byref(inv))
         row = np.zeros(36, dtype=f32)
         # shape 1 = general rect, 2 = axis-aligned rect (identity matrix, signed unit axes), 3 = such a rect whose
-        # world normal is a signed unit axis too; | 4 = cuboid face
+        # world normal is a signed unit axis too, 4 = signed unit LOCAL axes under any transform; | 8 = cuboid face
         identity = [tf.cx.x, tf.cx.y, tf.cx.z, tf.cy.x, tf.cy.y, tf.cy.z, tf.cz.x, tf.cz.y, tf.cz.z] == [1, 0, 0, 0, 1, 0, 0, 0, 1]
         au, av = unit_axis(r.x), unit_axis(r.y)
-        shape = 2 if (identity and au >= 0 and av >= 0) else 1
+        shape = 4 if (au >= 0 and av >= 0 and au != av) else 1     # 4: local axes are signed unit vectors, any transform
+        if identity and au >= 0 and av >= 0:
+            shape = 2
         nrm = xf_vector(tf, v(r.z))
         aw = unit_axis(o.V3(*[float(x) for x in nrm]))
         if shape == 2 and au != av and aw >= 0 and aw not in (au, av):
             shape = 3
-        kind = shape | (4 if strict else 0)
+        kind = shape | (8 if strict else 0)
         if shape >= 2:
             row[19:20].view(np.int32)[:] = au
             row[23:24].view(np.int32)[:] = av
@@ -89,6 +91,10 @@ def _expected_prims(o, sc):
         row[12:15], row[15] = v(inv.cx), f32(r.half_height) * f32(r.half_height)
         row[16:19], row[20:23], row[24:27] = v(inv.cy), v(inv.cz), v(inv.t)
         row[28:31], row[32:35] = v(r.x), v(r.y)
+        if shape == 4:       # rows u, v of the inverse transform (with its translation) instead of Rect.x / Rect.y
+            comp = lambda a, i: [a.x, a.y, a.z][i]
+            row[28:32] = [comp(inv.cx, au), comp(inv.cy, au), comp(inv.cz, au), comp(inv.t, au)]
+            row[32:36] = [comp(inv.cx, av), comp(inv.cy, av), comp(inv.cz, av), comp(inv.t, av)]
         return row
 
     for oi in range(sc.c.n_objects):
