@@ -263,6 +263,17 @@ def test_every_slice_count_gives_the_same_frame(bendy, oracle, monkeypatch, slic
     assert np.array_equal(out.numpy(), it)
 
 
+@pytest.mark.parametrize("max_wait", [0, 1, 2, 7])
+@pytest.mark.parametrize("name,w,h,spp", [("scene", 96, 54, 24), ("cloud", 64, 48, 12)])
+def test_phase_vote_is_scheduling_only(bendy, oracle, monkeypatch, name, w, h, spp, max_wait):
+    """Sphere-only builds vote every iteration between the camera event and the scatter / volume events; the losing
+    lanes keep their state for at most BT_PHASE_VOTE iterations (0 = no vote).  Same operations per lane, same bits."""
+    monkeypatch.setenv("BT_PHASE_VOTE", str(max_wait))
+    buf, stats, _ = gpu_render(bendy, name, w, h, spp)
+    it, seg = oracle_render(oracle, name, w, h, spp)
+    assert stats.segments == seg and np.array_equal(buf.numpy(), it)
+
+
 def test_render_deeper_than_the_scratch_is_split_into_launches(bendy, oracle, monkeypatch):
     """A render whose parked samples would not fit the scratch cap is issued as several launches over consecutive
     sample ranges (bt_api.cpp); BT_SCRATCH_CAP shrinks the cap so that 40 samples need 4 launches (12+12+12+4)."""
