@@ -112,8 +112,9 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
     // workgroup owns one block: its pxb * T (pixel, sample) pairs are work items i = k * pxb + pixel, handed out
     // through an LDS counter (one atomic per wave and iteration, see the loop) -- a lane whose path has ended takes
     // the next item, so all 256 lanes stay busy until the block's samples run out, and 64 consecutive items are the
-    // same sample of neighbouring pixels (coherent camera rays).  Every sample's value is parked at scratch[(block * T + k) * pxb + pixel]; the last wave to finish adds
-    // them to the frame in sample order (end of the kernel).
+    // same sample of neighbouring pixels (coherent camera rays).  Every sample's value is parked at
+    // scratch[(block * T + k) * pxb + pixel]; the last wave to finish adds them to the frame in sample order (end of
+    // the kernel).
     const uint32_t NS = SLICED ? (uint32_t)P.slices : 1u;
     const uint32_t pxb = 256u / NS;                    // pixels per block
     const uint32_t bi = blockIdx.x;                    // block index in launch order
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_S
     const uint32_t T = (uint32_t)P.samples * nn;       // samples per pixel in this launch
     const uint32_t sample0 = P.sample_base * nn;
 
-    // the lane's current pixel and sample: fixed pixel / k = 0, 1, ... when !SLICED, set by next_item() when SLICED
+    // the lane's current pixel and sample: fixed pixel / k = 0, 1, ... when !SLICED, taken from the queue when SLICED
     uint32_t px, py, pixel_index, k = 0;
     float4 *park = nullptr;                            // SLICED: where the current sample's value goes
     float *out_px = nullptr;
