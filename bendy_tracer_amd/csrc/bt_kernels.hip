@@ -51,6 +51,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #ifndef BT_WAVES_PER_SIMD
 #define BT_WAVES_PER_SIMD 6
 #endif
+#ifndef BT_WAVES_PER_SIMD_RECTS
+#define BT_WAVES_PER_SIMD_RECTS 7      // scenes with rects are TRACE-bound, their builds gain from a seventh wave (72 VGPRs):
+#endif                                 // Cornell 12.05 -> 11.6 ms, profiles/r01g/ab_w567_vote.log
 #ifndef BT_WAVES_PER_SIMD_LENS
 #define BT_WAVES_PER_SIMD_LENS 4       // the lens builds carry the RK4 state: 128 VGPRs, no scratch
 #endif
@@ -63,7 +66,7 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // RECTS = false: sphere-only scenes (scene.json, volume.json, cloud.json) run a build without any rect / cuboid code.
 // VOLS = false: no sphere carries a volume (scene.json, the Cornell boxes): the march and Volume::shade drop out.
 template <int OUTPUT, bool LENS, bool SLICED, bool RECTS, bool VOLS>
-__global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : BT_WAVES_PER_SIMD) void bt_render_kernel(BtLaunch P) {
+__global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : BT_WAVES_PER_SIMD)) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_waves_done;      // SLICED: waves of this workgroup that have parked all their samples
     __shared__ uint32_t s_next_item;       // SLICED: the workgroup's work queue (next unclaimed (pixel, sample) pair)
