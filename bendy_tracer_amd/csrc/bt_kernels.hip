@@ -55,8 +55,8 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #define BT_WAVES_PER_SIMD_RECTS 7      // scenes with rects are TRACE-bound, their builds gain from a seventh wave (72 VGPRs):
 #endif                                 // Cornell 12.05 -> 11.6 ms, profiles/r01g/ab_w567_vote.log
 #ifndef BT_WAVES_PER_SIMD_LENS
-#define BT_WAVES_PER_SIMD_LENS 4       // the lens builds carry the RK4 state: 128 VGPRs, no scratch
-#endif
+#define BT_WAVES_PER_SIMD_LENS 6       // lens builds: 80 VGPRs + ~100 B of scratch per lane still beat 4 waves without
+#endif                                 // scratch (665 -> 719 Msamples/s, profiles/r01g/ab_lens_waves.log)
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
 #ifndef BT_LENS_BATCH
 #define BT_LENS_BATCH 8            // RK4 steps a lane marches per loop iteration before it yields
