@@ -325,11 +325,13 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     const uint32_t grid = sharded ? (n_tiles + world - 1) / world : n_tiles;
 
-    // Sample slicing (BtLaunch::slices): S slices of >= 16 samples each where the pixel count alone gives fewer
-    // than ~6 rounds of resident waves or the launch is long enough for its tail to matter; measured on MI355X
-    // (profiles/r01d): C3 6.26 -> ~4.9 ms with S = 4, a world-8 shard (512 spp) 20.3 -> ~5 ms with S = 16.
-    // Scratch = 16 B per sample of the launch; a render that would need more than BT_SCRATCH_CAP is issued as
-    // several launches over consecutive sample ranges (k launches of m samples == one launch of k * m samples).
+    // Shape of the launch.  More than one ray per pixel -> the work-queue kernel: a workgroup owns a
+    // block of 256 / S pixels and deals their samples to its lanes, every sample's value is parked in `scratch`
+    // (16 B per sample of the launch).  S is chosen so that a workgroup holds ~16 samples per lane (4 with the lens on,
+    // whose paths differ far more in length; down to 4 as well when the launch has too few pixels to fill the GPU).
+    // A render whose scratch would exceed the cap is issued as several launches over consecutive sample ranges
+    // (k launches of m samples == one launch of k * m samples).  One ray per pixel, or no memory for the scratch ->
+    // the lanes kernel, which needs none.  Environment knobs are for A/B measurements and tests only.
     const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
     const uint64_t px_launch = (uint64_t)grid * BT_TILE_DIM * BT_TILE_DIM;
     uint32_t chunk = (uint32_t)P.samples;                         // samples per launch
@@ -337,32 +339,26 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     P.scratch = nullptr;
     {
         uint64_t cap = 8ull << 30;
-        if (const char *e = getenv("BT_SCRATCH_CAP")) cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // bytes; tests
-        auto pick = [&](uint64_t T) {
+        if (const char *e = getenv("BT_SCRATCH_CAP")) cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        const char *forced_s = getenv("BT_SLICES");                // 1, 2, 4, 8, 16, 32
+        auto pick = [&](uint64_t T) -> uint32_t {
+            if (forced_s) {
+                const int v = atoi(forced_s);
+                if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) return (uint32_t)v;
+            }
             uint32_t S = 1;
-            const uint64_t per_lane = P.lens_on ? 4 : 16;          // bent paths differ far more in length: balance earlier
-            while (S < 32 && T / (2 * S) >= per_lane) S *= 2;      // >= 16 samples per lane of the workgroup
-            const uint64_t waves = (uint64_t)grid * 4;             // too few pixels to fill the GPU: go down to 4 per slice
+            const uint64_t per_lane = P.lens_on ? 4 : 16;
+            while (S < 32 && T / (2 * S) >= per_lane) S *= 2;
+            const uint64_t waves = (uint64_t)grid * 4;
             while (S < 16 && waves * S < 4 * 5120 && T / (2 * S) >= 4) S *= 2;
             return S;
         };
-        uint32_t S = pick((uint64_t)chunk * nn);
-        if (const char *e = getenv("BT_SLICES")) {                 // A/B knob: 1, 2, 4, 8, 16, 32
-            const int v = atoi(e);
-            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) S = (uint32_t)v;
-        }
-        // the work-queue kernel whenever a pixel gets more than one sample in this launch (also with whole tiles, S = 1:
-        // the reference's interactive pattern, 1 sample x Subpixel(2) per call, gains 2-18 % from the balancing alone,
-        // profiles/r01e/time_progressive.log); the lanes kernel for one ray per pixel
         bool queue = (uint64_t)chunk * nn >= 2;
-        if (const char *e = getenv("BT_QUEUE")) queue = atoi(e) != 0;   // A/B knob: the queue with whole tiles (S = 1)
+        if (const char *e = getenv("BT_QUEUE")) queue = atoi(e) != 0;
         if (queue) {
             const uint64_t per_sample = px_launch * nn * 4 * sizeof(float);
             if (per_sample * chunk > cap) chunk = (uint32_t)std::max<uint64_t>(1, cap / per_sample);
-            if (chunk < (uint32_t)P.samples && !getenv("BT_SLICES")) S = pick((uint64_t)chunk * nn);
-        }
-        if (queue) {
-            const uint64_t need = px_launch * nn * chunk * 4 * sizeof(float);
+            const uint64_t need = per_sample * chunk;
             if (s->scratch_bytes < need) {
                 if (s->d_scratch) (void)hipFree(s->d_scratch);
                 s->d_scratch = nullptr;
@@ -370,14 +366,13 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
                 if (hipMalloc((void **)&s->d_scratch, need) == hipSuccess) {
                     s->scratch_bytes = need;
                 } else {
-                    (void)hipGetLastError();              // no room for the scratch: the lanes kernel needs none
-                    s->d_scratch = nullptr;
+                    (void)hipGetLastError();
                     queue = false;
                 }
             }
         }
         if (queue) {
-            P.slices = (int32_t)S;
+            P.slices = (int32_t)pick((uint64_t)chunk * nn);
             P.scratch = s->d_scratch;
         } else {
             chunk = (uint32_t)P.samples;
