@@ -80,6 +80,33 @@ def cpu_baseline(scene_name, w, h, budget_s=15.0):
     }
 
 
+def parity_figure(b, torch, scene_name, w=240, h=135, spp=16):
+    """The second half of BASELINE.json's metric, "max |delta pixel| vs CPU ref": a small frame of the same scene rendered
+    by the HIP path and by the CPU oracle (checker only).  Mean-framebuffer difference per channel against the oracle's
+    recursive form (products nested as the reference nests them), and bit-identity with its iterative form."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bt_oracle_py as o
+    path = os.path.join(ROOT, "scenes", f"{scene_name}.json.gz")
+    sc = b.Scene.load(path)
+    cam = sc.find_by_tag("camera")
+    sc.set_camera_aspect(cam, w / h)
+    buf = b.Buffer.new(w, h)
+    b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4)).render(sc, cam, b.RenderConfig.with_samples(spp), buf, seed=SEED)
+    torch.cuda.synchronize()
+    got = buf.numpy()
+    osc = o.Scene.load(path)
+    ocam = osc.find_by_tag("camera")
+    osc.set_camera_aspect(ocam, w / h)
+    rec, _, _ = o.render(osc, ocam, o.default_config(samples=spp, recursive=1), w, h, SEED, nthreads=8)
+    it, _, _ = o.render(osc, ocam, o.default_config(samples=spp, recursive=0), w, h, SEED, nthreads=8)
+    return {"frame": f"{scene_name}.json.gz {w}x{h}x{spp}spp", "tolerance": 1e-4,
+            "max_abs_delta_mean_vs_cpu_recursive_form": float(np.abs(got[..., :3] - rec[..., :3]).max() / spp),
+            "bit_identical_to_cpu_iterative_form": bool(np.array_equal(got, it)),
+            "note": "CPU ref = this repo's C restatement of the reference algorithm (the Rust binary cannot be built here and "
+                    "seeds from OS entropy); full-size parity is in tests/test_gpu_parity.py"}
+
+
 def load_pmc_traffic(workload):
     """HBM bytes per launch from a committed rocprofv3 --pmc run (profiles/pmc_traffic.json)."""
     try:
@@ -308,6 +335,7 @@ def main():
             out["lens_extension"] = lens_extension_rate(b, torch, scene_name, w, h)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_name, w, h, args.cpu_budget)
+            out["parity"] = parity_figure(b, torch, scene_name)
         print(json.dumps(out), flush=True)
     if dist_path:
         dist.barrier()
