@@ -371,9 +371,24 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
                 }
             }
         }
+        P.tiles_per_wg = 1;
         if (queue) {
             P.slices = (int32_t)pick((uint64_t)chunk * nn);
             P.scratch = s->d_scratch;
+            // shallow launches (the interactive pattern, 1 sample x Subpixel(2) per call): whole tiles, two or four per
+            // workgroup, so that a lane still gets ~8 items -- while the launch keeps >= 2 rounds of workgroups.  Pays
+            // where samples are cheap (scene.json 0.58 -> 0.48 ms per 1080p call); with rects or volumes four items
+            // are work enough and fewer workgroups only lengthen the tail (profiles/r01g/time_progressive_tpw.log).
+            const uint64_t T = (uint64_t)chunk * nn;
+            uint32_t tpw = 1;
+            while (P.slices == 1 && !P.any_rects && !P.any_volumes && tpw < 4 && 256ull * (2 * tpw) * T <= 4096 &&
+                   grid / (2 * tpw) >= 3584)
+                tpw *= 2;
+            if (const char *e = getenv("BT_TILES_PER_WG")) {
+                const int v = atoi(e);
+                if (P.slices == 1 && (v == 1 || v == 2 || v == 4)) tpw = (uint32_t)v;
+            }
+            P.tiles_per_wg = (int32_t)tpw;
         } else {
             chunk = (uint32_t)P.samples;
         }

@@ -118,13 +118,28 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     // same sample of neighbouring pixels (coherent camera rays).  Every sample's value is parked at
     // scratch[(block * T + k) * pxb + pixel]; the last wave to finish adds them to the frame in sample order (end of
     // the kernel).
+    // Shallow launches (T <= 8) go the other way: a workgroup owns TPW = 2 or 4 whole tiles (NS = 1), so that a lane
+    // still gets ~8 items and the drain at the end of a workgroup stays short (BtLaunch::tiles_per_wg).
     const uint32_t NS = SLICED ? (uint32_t)P.slices : 1u;
-    const uint32_t pxb = 256u / NS;                    // pixels per block
+    const uint32_t TPW = SLICED ? (uint32_t)P.tiles_per_wg : 1u;
+    const uint32_t pxb = 256u * TPW / NS;              // pixels per block
     const uint32_t bi = blockIdx.x;                    // block index in launch order
-    const uint32_t slot = bi / NS, sub = bi % NS;      // tile slot, block within the tile
-    const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
-    const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     const uint32_t lane = threadIdx.x & 63;
+    // pixel q of this workgroup's block: frame coordinates, whether it exists, and where its running sum lives
+    struct PixelRef { uint32_t px, py; bool in_frame; float *out; };
+    auto locate = [&](uint32_t q) -> PixelRef {
+        const uint32_t slot = TPW > 1 ? bi * TPW + (q >> 8) : bi / NS;              // tile slot in launch order
+        const BlockPixel b = TPW > 1 ? block_pixel(0, q & 255u, 256u) : block_pixel(bi % NS, q, pxb);
+        const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
+        const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+        PixelRef r;
+        r.px = tx * BT_TILE_DIM + b.x;
+        r.py = ty * BT_TILE_DIM + b.y;
+        r.in_frame = (ty < P.tiles_y) && (r.px < P.width) && (r.py < P.height);
+        r.out = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + b.y * BT_TILE_DIM + b.x) * 4
+                          : P.out + ((size_t)r.py * P.width + r.px) * 4;
+        return r;
+    };
     const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
     const uint32_t T = (uint32_t)P.samples * nn;       // samples per pixel in this launch
     const uint32_t sample0 = P.sample_base * nn;
@@ -140,13 +155,12 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         px = py = pixel_index = 0;
         alive = true;                                  // until the workgroup's queue is empty (see the loop)
     } else {
-        const BlockPixel b = block_pixel(0, threadIdx.x, 256);
-        px = tx * BT_TILE_DIM + b.x;
-        py = ty * BT_TILE_DIM + b.y;
+        const PixelRef r = locate(threadIdx.x);
+        px = r.px;
+        py = r.py;
         pixel_index = py * P.width + px;
-        out_px = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + b.y * BT_TILE_DIM + b.x) * 4
-                           : P.out + ((size_t)py * P.width + px) * 4;
-        alive = (ty < P.tiles_y) && (px < P.width) && (py < P.height);
+        out_px = r.out;
+        alive = r.in_frame;
         if (alive) acc = mk(out_px[0], out_px[1], out_px[2]);            // `*r += pixel.r` (buffer.rs:159-164)
     }
     const bool in_frame = alive;                       // !SLICED: this lane's pixel exists
@@ -333,10 +347,10 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     if (i >= n_items) break;                              // the block's samples are all taken
                     const uint32_t q = i & (pxb - 1);
                     k = i / pxb;
-                    const BlockPixel b = block_pixel(sub, q, pxb);
-                    px = tx * BT_TILE_DIM + b.x;
-                    py = ty * BT_TILE_DIM + b.y;
-                    if (!((ty < P.tiles_y) && (px < P.width) && (py < P.height))) {
+                    const PixelRef r = locate(q);
+                    px = r.px;
+                    py = r.py;
+                    if (!r.in_frame) {
                         pending = true;                                   // pixel outside the frame (edge tile): skip it
                         continue;
                     }
@@ -560,11 +574,9 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (pxb >= 64) {
                 for (uint32_t q = lane; q < pxb; q += 64) {
-                    const BlockPixel b2 = block_pixel(sub, q, pxb);
-                    const uint32_t qx = tx * BT_TILE_DIM + b2.x, qy = ty * BT_TILE_DIM + b2.y;
-                    if (!((ty < P.tiles_y) && (qx < P.width) && (qy < P.height))) continue;
-                    float *o = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + b2.y * BT_TILE_DIM + b2.x) * 4
-                                         : P.out + ((size_t)qy * P.width + qx) * 4;
+                    const PixelRef r = locate(q);
+                    if (!r.in_frame) continue;
+                    float *o = r.out;
                     const float4 *src = (const float4 *)P.scratch + (size_t)bi * T * pxb + q;
                     V3 sum = mk(o[0], o[1], o[2]);
                     uint32_t kk = 0;
@@ -587,11 +599,9 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 // 32, 16 or 8 pixels (deep launches, T in the hundreds): J = 64 / pxb lanes per pixel fetch interleaved
                 // samples (8 J in flight per pixel), lane (q, 0) adds them in sample order out of the others' registers
                 const uint32_t J = 64u / pxb, q = lane % pxb, jl = lane / pxb;
-                const BlockPixel b2 = block_pixel(sub, q, pxb);
-                const uint32_t qx = tx * BT_TILE_DIM + b2.x, qy = ty * BT_TILE_DIM + b2.y;
-                const bool owner = jl == 0 && (ty < P.tiles_y) && (qx < P.width) && (qy < P.height);
-                float *o = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + b2.y * BT_TILE_DIM + b2.x) * 4
-                                     : P.out + ((size_t)qy * P.width + qx) * 4;
+                const PixelRef r = locate(q);
+                const bool owner = jl == 0 && r.in_frame;
+                float *o = r.out;
                 const float4 *src = (const float4 *)P.scratch + (size_t)bi * T * pxb + q;
                 V3 sum = mk(0.0f, 0.0f, 0.0f);
                 if (owner) sum = mk(o[0], o[1], o[2]);
@@ -709,7 +719,8 @@ __global__ __launch_bounds__(256) void bt_preview_kernel(const float4 *rgba, uin
 extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream) {
     // grid = tiles to render; with sample slicing a tile is S workgroups (see the mapping in the kernel)
-    dim3 g(grid * (unsigned)P->slices), b(256);
+    const unsigned tpw = P->scratch ? (unsigned)P->tiles_per_wg : 1u;
+    dim3 g(tpw > 1 ? (grid + tpw - 1) / tpw : grid * (unsigned)P->slices), b(256);
     const bool sliced = P->scratch != nullptr;      // the work-queue instantiation (any S, also whole tiles)
     // scene classes: bit 0 = some sphere carries a volume (volume.json, cloud.json), bit 1 = rects / cuboids present
     // (the Cornell boxes); scene.json is class 0

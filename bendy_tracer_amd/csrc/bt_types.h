@@ -150,6 +150,7 @@ struct BtLaunch {
     // scratch[(block * T + k) * (256/S) + pixel] (float4, T = samples * n^2) and the last wave of the workgroup to
     // finish adds them to the frame in sample order -- same additions, same order, same bits as slices = 1.
     int32_t slices;                   // 1 = a lane owns all samples of its pixel (no scratch)
+    int32_t tiles_per_wg;             // work-queue kernel, shallow launches: a workgroup owns 1, 2 or 4 whole tiles (slices == 1)
     float *scratch;
     // Phase voting (bt_kernels.hip, sphere-only builds): every iteration the wave runs EITHER the camera event OR the
     // scatter / volume events, whichever more of its lanes want; the others keep what they have (no ray yet, or their

@@ -263,6 +263,35 @@ def test_every_slice_count_gives_the_same_frame(bendy, oracle, monkeypatch, slic
     assert np.array_equal(out.numpy(), it)
 
 
+@pytest.mark.parametrize("tiles", [1, 2, 4])
+@pytest.mark.parametrize("world", [1, 3])
+def test_several_tiles_per_workgroup(bendy, oracle, monkeypatch, tiles, world):
+    """Shallow launches give a workgroup 2 or 4 whole tiles (BtLaunch::tiles_per_wg; BT_TILES_PER_WG forces it): ragged
+    frame, an odd number of tiles, full-frame and sharded layout, the interactive pattern (1 sample x Subpixel(2))."""
+    import torch
+    monkeypatch.setenv("BT_TILES_PER_WG", str(tiles))
+    w, h = 150, 75                                   # 10 x 5 tiles, ragged right / bottom edge
+    it, _ = oracle_render(oracle, "cornell2", w, h, 1, n=2)
+    sc, cam = gpu_scene(bendy, "cornell2", w, h)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    rc = bendy.RenderConfig.with_samples_subsample(1, bendy.Subsample(2))
+    if world == 1:
+        buf = bendy.Buffer.new(w, h)
+        tr.render(sc, cam, rc, buf)
+        torch.cuda.synchronize()
+        assert sc.last_stats().slices == 1 and np.array_equal(buf.numpy(), it)
+    else:
+        shards = []
+        for r in range(world):
+            s = bendy.new_shard(w, h, world)
+            tr.render_shard(sc, cam, rc, s, w, h, r, world)
+            shards.append(s)
+        out = bendy.Buffer.new(w, h)
+        bendy.unshard(torch.cat(shards), out, world)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.numpy(), it)
+
+
 @pytest.mark.parametrize("max_wait", [0, 1, 2, 7])
 @pytest.mark.parametrize("name,w,h,spp", [("scene", 96, 54, 24), ("cloud", 64, 48, 12)])
 def test_phase_vote_is_scheduling_only(bendy, oracle, monkeypatch, name, w, h, spp, max_wait):

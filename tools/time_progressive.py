@@ -8,14 +8,13 @@ w, h = 1920, 1080
 for name in ('scene', 'cornell2', 'volume'):
     sc = b.Scene.load(f'scenes/{name}.json.gz'); cam = sc.find_by_tag('camera'); sc.set_camera_aspect(cam, w / h)
     tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
-    for mode in ('auto', '1', 'q1', '2'):          # q1 = the work queue over whole 16x16 tiles (BT_QUEUE=1, S = 1)
-        os.environ.pop('BT_SLICES', None)
+    for mode in ('auto', 't1', 't2', 't4', 'lanes'):   # tN = N whole tiles per workgroup; lanes = no work queue
+        os.environ.pop('BT_TILES_PER_WG', None)
         os.environ.pop('BT_QUEUE', None)
-        if mode == 'q1':
-            os.environ['BT_SLICES'] = '1'
-            os.environ['BT_QUEUE'] = '1'
+        if mode == 'lanes':
+            os.environ['BT_QUEUE'] = '0'
         elif mode != 'auto':
-            os.environ['BT_SLICES'] = mode
+            os.environ['BT_TILES_PER_WG'] = mode[1:]
         buf = b.Buffer.new(w, h)
         rc = b.RenderConfig.with_samples_subsample(1, b.Subsample(2))
         for i in range(5):
