@@ -9,11 +9,13 @@
 //   march (volume.rs) -> `+=` into the RGBA32F accumulator (buffer.rs:159-178).
 //
 // Mapping to the hardware:
-//   * a workgroup owns a block of 256/S pixels (S = 1..16) and all of their samples in this launch.  For S > 1
-//     (the default for launches with >= 8 samples per pixel) the block's (pixel, sample) pairs are a work queue in
-//     LDS: a lane whose path has ended takes the next pair, every sample's value is parked in HBM and the last
-//     wave of the workgroup adds the parked values to the frame in sample order -- the reference's per-pixel
-//     summation order, no atomics on the frame.  For S = 1 a lane owns one pixel and sums in a register;
+//   * a workgroup owns a block of 256/S pixels (S = 1..32; or 2 / 4 whole tiles for very shallow launches) and all
+//     of their samples in this launch.  Whenever a pixel gets more than one ray the block's (pixel, sample) pairs are
+//     a work queue in LDS: a lane whose path has ended takes the next pair, every sample's value is parked in HBM and
+//     the last wave of the workgroup adds the parked values to the frame in sample order -- the reference's per-pixel
+//     summation order, no atomics on the frame.  With one ray per pixel a lane owns one pixel and sums in a register;
+//   * in the sphere-only builds a wave votes every iteration whether it runs the camera event or the scatter / volume
+//     events; the lanes of the other kind keep their state for the next iteration (phase voting);
 //   * every loop iteration is TRACE (one path segment, all lanes) followed by exactly ONE random event per lane --
 //     a Diffuse / Metallic / Glass scatter, a volume step, or, for a lane whose path just ended, the camera ray of
 //     its next sample.  The event's Philox block, its sin/cos, its basis construction and its final normalize are
