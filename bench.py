@@ -329,7 +329,8 @@ def main():
             "note": "byte model of SURVEY 8(d): 128 B per path segment (wavefront SoA ray state) + 16 B per pixel; "
                     "the shipped kernel keeps ray state in registers, so real HBM traffic (`traffic`: 16 B per sample "
                     "parked and read back once + 32 B/pixel of frame) is ~15% of the model and the kernel is "
-                    "VALU-bound, not HBM-bound (DESIGN.md 'Roofline')",
+                    "VALU-bound, not HBM-bound (DESIGN.md 'Roofline'); frac > 1 therefore only says that the kernel is "
+                    "faster than any kernel that really moved the model's traffic could be",
         }
         if verified is not None:
             out["verified_vs_single_rank"] = verified
