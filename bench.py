@@ -117,6 +117,14 @@ def load_pmc_traffic(workload):
         return None
 
 
+def load_pmc_valu(workload):
+    """VALU counters of the same committed PMC run: what actually bounds the kernel."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload + "_valu")
+    except Exception:
+        return None
+
+
 def lens_extension_rate(b, torch, scene_name, w, h, spp=64, steps=2):
     """Throughput of the same frame with the gravitational-lens EXTENSION switched on.  Not part of `value`:
     the reference has no lens code, so this mode has no reference behaviour and no parity claim
@@ -324,6 +332,7 @@ def main():
                 "true" if spp >= 2 else "false", *{"scene": ("false", "false"), "volume": ("false", "true")}.get(scene_name, ("true", "false"))),
             "kernel_ms": round(k_ms, 4), "slices": scene.last_stats().slices,
             "render_stream_ms_per_step_timed_region": round(statistics.mean(step_ms), 4),
+            "valu_pmc": load_pmc_valu(args.workload) if world == 1 else None,
             "segments_per_launch": int(seg), "segments_per_sample": round(seg / (my_pixels * spp), 4),
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "note": "byte model of SURVEY 8(d): 128 B per path segment (wavefront SoA ray state) + 16 B per pixel; "
