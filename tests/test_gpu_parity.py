@@ -303,6 +303,20 @@ def test_phase_vote_is_scheduling_only(bendy, oracle, monkeypatch, name, w, h, s
     assert stats.segments == seg and np.array_equal(buf.numpy(), it)
 
 
+def test_one_deep_call_equals_many_shallow_calls(bendy):
+    """Size-independent property (main.rs:245-254 accumulates call after call): 2048 samples in one call -- pixel blocks
+    of 4x2, hundreds of items per lane -- give the bits of 32 calls of 64 samples."""
+    w, h = 320, 180
+    deep, st, _ = gpu_render(bendy, "scene", w, h, 2048)
+    assert st.slices == 32
+    sc, cam = gpu_scene(bendy, "scene", w, h)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    buf = bendy.Buffer.new(w, h)
+    for _ in range(32):
+        tr.render(sc, cam, bendy.RenderConfig.with_samples(64), buf)
+    assert buf.samples == 2048 and np.array_equal(buf.numpy(), deep.numpy())
+
+
 def test_render_deeper_than_the_scratch_is_split_into_launches(bendy, oracle, monkeypatch):
     """A render whose parked samples would not fit the scratch cap is issued as several launches over consecutive
     sample ranges (bt_api.cpp); BT_SCRATCH_CAP shrinks the cap so that 40 samples need 4 launches (12+12+12+4)."""
