@@ -182,17 +182,19 @@ BT_DEV bool sphere_t(V3 o, V3 d, V3 c, float radius, float tmin, float tmax, flo
 template <int W, class PrimRef>
 BT_DEV bool rect_aan_t(V3 o, V3 d, PrimRef &R, float tmin, float tmax, bool strict, float &t_out, float &q_out, float &p_out) {
     constexpr int A = W == 0 ? 1 : 0, B = W == 2 ? 1 : 2;
+    // Branch-free: every test is evaluated and AND-ed (a rejected lane's t may be inf / NaN -- it is never used).
+    // Rect scenes issue almost as many scalar as vector instructions (exec-mask bookkeeping of nested early returns,
+    // one scalar issue per cycle and CU); the wave almost never skips a block as a whole anyway.
     const float dq = BT_COMP(d, W);
-    if (fabsf(dq) <= 1e-5f) return false;
     const float dp = BT_COMP(R.t, W) - BT_COMP(o, W);
     const float t = dp / dq;                      // == dot(t - o, n) / dot(d, n), the signs of n cancel exactly
-    if (t < tmin || t > tmax) return false;
-    if (strict && !(t < tmax)) return false;
     const float la = (BT_COMP(o, A) + BT_COMP(d, A) * t) + BT_COMP(R.it, A);
     const float lb = (BT_COMP(o, B) + BT_COMP(d, B) * t) + BT_COMP(R.it, B);
     const bool u_is_a = R.aa_u == A;
     const float lim_a = u_is_a ? R.w_sqr : R.h_sqr, lim_b = u_is_a ? R.h_sqr : R.w_sqr;
-    if (!(la * la <= lim_a && lb * lb <= lim_b)) return false;
+    const bool ok = !(fabsf(dq) <= 1e-5f) & !(t < tmin || t > tmax) & !(strict && !(t < tmax)) &
+                    (la * la <= lim_a) & (lb * lb <= lim_b);
+    if (!ok) return false;
     const float sgn = BT_COMP(R.c, W);            // +-1
     t_out = t;
     q_out = dq * sgn;
