@@ -211,13 +211,12 @@ BT_DEV bool rect_t(V3 o, V3 d, PrimRef &R, float tmin, float tmax, bool strict, 
         if (w == 1) return rect_aan_t<1>(o, d, R, tmin, tmax, strict, t_out, q_out, p_out);
         return rect_aan_t<2>(o, d, R, tmin, tmax, strict, t_out, q_out, p_out);
     }
+    // general and local-axes rects: branch-free as well (see rect_aan_t)
     V3 n = mk(R.c);
     float q = dot(d, n);
-    if (fabsf(q) <= 1e-5f) return false;
     float p = dot(mk(R.t) - o, n);
     float t = p / q;
-    if (t < tmin || t > tmax) return false;
-    if (strict && !(t < tmax)) return false;     // Cuboid::hit keeps `manifold.t < t` (cuboid.rs:96)
+    bool ok = !(fabsf(q) <= 1e-5f) & !(t < tmin || t > tmax) & !(strict && !(t < tmax));   // cuboid.rs:96 keeps `manifold.t < t`
     V3 pos = o + d * t;
     if ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_RECT_AA) {
         // identity matrix, Rect.x = +-e_u, Rect.y = +-e_v: `M^-1*pos + t'` is pos + t' and each
@@ -227,21 +226,23 @@ BT_DEV bool rect_t(V3 o, V3 d, PrimRef &R, float tmin, float tmax, bool strict, 
         const int u = R.aa_u, v = R.aa_v;
         float lu = (u == 0 ? pos.x : (u == 1 ? pos.y : pos.z)) + (u == 0 ? R.it.x : (u == 1 ? R.it.y : R.it.z));
         float lv = (v == 0 ? pos.x : (v == 1 ? pos.y : pos.z)) + (v == 0 ? R.it.x : (v == 1 ? R.it.y : R.it.z));
-        if (!(lu * lu <= R.w_sqr && lv * lv <= R.h_sqr)) return false;
+        ok = ok & (lu * lu <= R.w_sqr) & (lv * lv <= R.h_sqr);
     } else if ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_RECT_LA) {
         // Rect.x = +-e_u, Rect.y = +-e_v in LOCAL space: the projections' squared lengths are local[u]^2, local[v]^2
         // (as above), so only those two components of `M^-1 * pos + t'` are formed -- component by component the
         // expression of xf_vector() + it; the host has put the two rows where Rect.x / Rect.y sit in other rows.
         const float lu = ((R.ax.x * pos.x + R.ax.y * pos.y) + R.ax.z * pos.z) + R.ax_w;     // rows u, v of M^-1 | t'
         const float lv = ((R.ay.x * pos.x + R.ay.y * pos.y) + R.ay.z * pos.z) + R.ay_w;
-        if (!(lu * lu <= R.w_sqr && lv * lv <= R.h_sqr)) return false;
+        ok = ok & (lu * lu <= R.w_sqr) & (lv * lv <= R.h_sqr);
     } else {
         V3 local = xf_vector(mk(R.icx), mk(R.icy), mk(R.icz), pos) + mk(R.it);
         V3 ax = mk(R.ax), ay = mk(R.ay);
         V3 px = ax * dot(local, ax);
         V3 py = ay * dot(local, ay);
-        if (!(len2(px) <= R.w_sqr && len2(py) <= R.h_sqr)) return false;
+        const bool in_u = len2(px) <= R.w_sqr, in_v = len2(py) <= R.h_sqr;
+        ok = ok & in_u & in_v;
     }
+    if (!ok) return false;
     t_out = t;
     q_out = q;
     p_out = p;
