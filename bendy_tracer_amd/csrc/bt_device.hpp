@@ -194,12 +194,11 @@ BT_DEV bool rect_aan_t(V3 o, V3 d, PrimRef &R, float tmin, float tmax, bool stri
     const float lim_a = u_is_a ? R.w_sqr : R.h_sqr, lim_b = u_is_a ? R.h_sqr : R.w_sqr;
     const bool ok = !(fabsf(dq) <= 1e-5f) & !(t < tmin || t > tmax) & !(strict && !(t < tmax)) &
                     (la * la <= lim_a) & (lb * lb <= lim_b);
-    if (!ok) return false;
     const float sgn = BT_COMP(R.c, W);            // +-1
     t_out = t;
     q_out = dq * sgn;
     p_out = dp * sgn;
-    return true;
+    return ok;
 }
 // Rect::hit up to the containment test (rect.rs:110-137); q and p returned for pdf / face.
 template <class PrimRef>
@@ -242,11 +241,10 @@ BT_DEV bool rect_t(V3 o, V3 d, PrimRef &R, float tmin, float tmax, bool strict, 
         const bool in_u = len2(px) <= R.w_sqr, in_v = len2(py) <= R.h_sqr;
         ok = ok & in_u & in_v;
     }
-    if (!ok) return false;
     t_out = t;
     q_out = q;
     p_out = p;
-    return true;
+    return ok;
 }
 
 struct HitRec {
@@ -293,13 +291,12 @@ BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int las
             }
         }
     } else {
-        float t, q, p;
-        if (rect_t(o, d, R, tmin, h.t, (R.kind & BT_PRIM_STRICT) != 0, t, q, p)) {
-            h.t = t;
-            h.prim = i;
-            h.inside = false;
-            h.p_neg = p < 0.0f;
-        }
+        float t = 0.0f, q = 0.0f, p = 0.0f;
+        const bool hit = rect_t(o, d, R, tmin, h.t, (R.kind & BT_PRIM_STRICT) != 0, t, q, p);
+        h.t = hit ? t : h.t;                    // selects, not a branch (scalar-issue pressure, see rect_aan_t)
+        h.prim = hit ? i : h.prim;
+        h.inside = hit ? false : h.inside;
+        h.p_neg = hit ? p < 0.0f : h.p_neg;
     }
 }
 // Sphere-only scenes: try_hit / try_hit_volume over BtSpherePair rows.  The clip-independent half of Sphere::hit
