@@ -179,9 +179,9 @@ std::vector<int32_t> lens_candidates(const std::vector<BtPrim> &prims, const bt_
                         m[r][c] = (a[r1][c1] * a[r2][c2] - a[r1][c2] * a[r2][c1]) / det;
                     }
                 const double hw = std::sqrt((double)R.w_sqr), hh = std::sqrt((double)R.h_sqr);
-                // local axes: Rect.x / Rect.y, which BT_PRIM_RECT_LA rows replace by rows of the inverse (bt_types.h)
+                // local axes: Rect.x / Rect.y, which BT_PRIM_RECT_LA / _AAN rows replace by other constants (bt_types.h)
                 double lx[3] = {R.ax.x, R.ax.y, R.ax.z}, ly[3] = {R.ay.x, R.ay.y, R.ay.z};
-                if ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_RECT_LA)
+                if ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_RECT_LA || (R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_RECT_AAN)
                     for (int i = 0; i < 3; ++i) {
                         lx[i] = i == R.aa_u ? 1.0 : 0.0;
                         ly[i] = i == R.aa_v ? 1.0 : 0.0;

@@ -185,16 +185,15 @@ BT_DEV bool rect_aan_t(V3 o, V3 d, PrimRef &R, float tmin, float tmax, bool stri
     // Branch-free: every test is evaluated and AND-ed (a rejected lane's t may be inf / NaN -- it is never used).
     // Rect scenes issue almost as many scalar as vector instructions (exec-mask bookkeeping of nested early returns,
     // one scalar issue per cycle and CU); the wave almost never skips a block as a whole anyway.
+    // the row's six constants sit side by side (bt_types.h): t[w], it[a], it[b], the two limits, c[w] = +-1
+    const float r_tw = R.ax.x, r_ia = R.ax.y, r_ib = R.ax.z, lim_a = R.ax_w, lim_b = R.ay.x, sgn = R.ay.y;
     const float dq = BT_COMP(d, W);
-    const float dp = BT_COMP(R.t, W) - BT_COMP(o, W);
+    const float dp = r_tw - BT_COMP(o, W);
     const float t = dp / dq;                      // == dot(t - o, n) / dot(d, n), the signs of n cancel exactly
-    const float la = (BT_COMP(o, A) + BT_COMP(d, A) * t) + BT_COMP(R.it, A);
-    const float lb = (BT_COMP(o, B) + BT_COMP(d, B) * t) + BT_COMP(R.it, B);
-    const bool u_is_a = R.aa_u == A;
-    const float lim_a = u_is_a ? R.w_sqr : R.h_sqr, lim_b = u_is_a ? R.h_sqr : R.w_sqr;
+    const float la = (BT_COMP(o, A) + BT_COMP(d, A) * t) + r_ia;
+    const float lb = (BT_COMP(o, B) + BT_COMP(d, B) * t) + r_ib;
     const bool ok = !(fabsf(dq) <= 1e-5f) & !(t < tmin || t > tmax) & !(strict && !(t < tmax)) &
                     (la * la <= lim_a) & (lb * lb <= lim_b);
-    const float sgn = BT_COMP(R.c, W);            // +-1
     t_out = t;
     q_out = dq * sgn;
     p_out = dp * sgn;

@@ -356,6 +356,12 @@ FlatScene flatten_scene(const Scene &sc) {
             if (au != av && aw >= 0 && aw != au && aw != av) {
                 shape = BT_PRIM_RECT_AAN;
                 p.aa_w = aw;
+                auto comp = [](BtV3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); };
+                const int a = aw == 0 ? 1 : 0, b = aw == 2 ? 1 : 2;          // in-plane axes, ascending
+                p.ax = v3(comp(p.t, aw), comp(p.it, a), comp(p.it, b));
+                p.ax_w = au == a ? p.w_sqr : p.h_sqr;
+                p.ay = v3(au == a ? p.h_sqr : p.w_sqr, comp(p.c, aw), 0.0f);
+                p.ay_w = 0.0f;
             }
         }
         p.kind = shape | (strict ? BT_PRIM_STRICT : 0);

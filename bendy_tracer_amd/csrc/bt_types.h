@@ -43,7 +43,9 @@ struct BtPrim {
     BtV3 icz; int32_t aa_v;     // BT_PRIM_RECT_AA: component index of Rect.y
     BtV3 it;  int32_t aa_w;     // BT_PRIM_RECT_AAN: component index of the normal
     // Rect.x, Rect.y (rect.rs:17-18); for BT_PRIM_RECT_LA rows instead the two rows of `M^-1 | t'` that the test
-    // needs: (ax, ax_w) = (icx[u], icy[u], icz[u], it[u]), (ay, ay_w) likewise for v
+    // needs: (ax, ax_w) = (icx[u], icy[u], icz[u], it[u]), (ay, ay_w) likewise for v; for BT_PRIM_RECT_AAN rows the six
+    // constants of rect_aan_t side by side (one scalar load): ax = (t[w], it[a], it[b]), ax_w = limit of a,
+    // ay = (limit of b, c[w] = +-1, 0), with a < b the two in-plane axes
     BtV3 ax;  float ax_w;
     BtV3 ay;  float ay_w;
 };

@@ -91,6 +91,12 @@ def _expected_prims(o, sc):
         row[12:15], row[15] = v(inv.cx), f32(r.half_height) * f32(r.half_height)
         row[16:19], row[20:23], row[24:27] = v(inv.cy), v(inv.cz), v(inv.t)
         row[28:31], row[32:35] = v(r.x), v(r.y)
+        if shape == 3:       # the six constants of the axis-aligned test side by side instead of Rect.x / Rect.y
+            comp = lambda a, i: [a.x, a.y, a.z][i]
+            a, b = (1 if aw == 0 else 0), (1 if aw == 2 else 2)
+            wq, hq = f32(r.half_width) * f32(r.half_width), f32(r.half_height) * f32(r.half_height)
+            row[28:32] = [comp(tf.t, aw), comp(inv.t, a), comp(inv.t, b), wq if au == a else hq]
+            row[32:36] = [hq if au == a else wq, float(nrm[aw]), 0.0, 0.0]
         if shape == 4:       # rows u, v of the inverse transform (with its translation) instead of Rect.x / Rect.y
             comp = lambda a, i: [a.x, a.y, a.z][i]
             row[28:32] = [comp(inv.cx, au), comp(inv.cy, au), comp(inv.cz, au), comp(inv.t, au)]
