@@ -397,9 +397,9 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     if (s->flat.lds_bytes() > 158 * 1024)
         return set_error(BT_ERR_INVALID_ARG, "scene tables (" + std::to_string(s->flat.lds_bytes()) +
                                                  " bytes) exceed the 160 KB of LDS of a gfx950 CU");
-    // longest wait in iterations (0 = no voting); measured best: 2 on scene.json, 4 on the volume scenes
-    // (profiles/r01f/ab_phase_vote.log)
-    P.phase_vote = P.any_volumes ? 4 : 2;
+    // longest wait in iterations (0 = no voting); measured best: 3 on scene.json, 4 on the volume scenes
+    // (profiles/r01f/ab_phase_vote.log, profiles/r01g/ab_vote_both.log)
+    P.phase_vote = P.any_volumes ? 4 : 3;
     if (const char *e = getenv("BT_PHASE_VOTE")) P.phase_vote = atoi(e);      // A/B knob
     BT_HIP(hipMemsetAsync(s->d_counters, 0, BT_N_COUNTERS * sizeof(unsigned long long), stream));
     BT_HIP(hipEventRecord(s->ev_start, stream));

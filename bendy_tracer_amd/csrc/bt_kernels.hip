@@ -318,11 +318,12 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             // (a third phase for the volume steps alone was tried and lost, profiles/r01f/ab_phase_vote.log)
             const bool want_gen = ev == EV_GEN;
             const unsigned long long m_gen = __ballot(want_gen), m_sc = __ballot(!want_gen);
-            bool gen_phase = __popcll(m_gen) >= __popcll(m_sc);
+            const bool gen_phase = __popcll(m_gen) >= __popcll(m_sc);
+            // a lane of the losing side that has waited long enough is served in THIS iteration together with the
+            // winners (both kinds run, as without the vote) -- the majority does not lose an iteration to it
             const unsigned long long starving = __ballot(waited >= P.phase_vote);
-            if (starving & m_sc) gen_phase = false;
-            else if (starving & m_gen) gen_phase = true;
-            if (want_gen != gen_phase) {
+            const bool both = (starving & (gen_phase ? m_sc : m_gen)) != 0;
+            if (want_gen != gen_phase && !both) {
                 waited += 1;
                 pending = want_gen;                   // no ray yet | the hit stays in held_t / held_info
                 held = !want_gen;
