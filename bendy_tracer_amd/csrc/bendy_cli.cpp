@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -69,6 +70,9 @@ struct Args {
     std::string save_scene;
     int device = 0;
     bool quiet = false;
+    unsigned samples_per_call = 1;                       // main.rs:248 renders 1 sample per displayed frame
+    bool no_screenshot = false;
+    std::string stats_json;                              // per-call kernel times / segment counts (profiling harness)
     bool has_lens = false;
     bt_lens lens{};
 };
@@ -78,6 +82,7 @@ void usage() {
                  "usage: bendy-tracer-hip --output <full|albedo|normal> [--width 768] [--height 512] [--samples 64]\n"
                  "       [--subsample 2] [--screenshot screenshots/render.png] [--scene scene.json]\n"
                  "       [--seed N] [--save-scene PATH] [--device N] [--quiet]\n"
+                 "       [--samples-per-call 1] [--no-screenshot] [--stats-json PATH]   (measurement harness)\n"
                  "       [--lens x,y,z,rs,step,radius[,max_steps]]   (extension: not in the reference)\n");
 }
 
@@ -104,6 +109,9 @@ Args parse(int argc, char **argv) {
         else if (k == "--save-scene") a.save_scene = val();
         else if (k == "--device") a.device = std::atoi(val().c_str());
         else if (k == "--quiet") a.quiet = true;
+        else if (k == "--samples-per-call") a.samples_per_call = std::max(1u, (unsigned)std::strtoul(val().c_str(), nullptr, 10));
+        else if (k == "--no-screenshot") a.no_screenshot = true;
+        else if (k == "--stats-json") a.stats_json = val();
         else if (k == "--lens") {
             const std::string spec = val();
             float f[7] = {0, 0, 0, 0, 0, 0, 4096};
@@ -174,9 +182,10 @@ int main(int argc, char **argv) {
     unsigned buffer_samples = 0;
     double sum_delta = 0.0;
     const auto start = std::chrono::steady_clock::now();
+    std::string per_call;                                  // --stats-json rows
     while (buffer_samples < args.samples) {
-        rc.samples = 1;
-        rc.sample_base = buffer_samples / nn;
+        rc.samples = std::min(args.samples_per_call, std::max(1u, (args.samples - buffer_samples) / nn));
+        rc.sample_base = (buffer_samples + nn - 1) / nn;
         const auto t0 = std::chrono::steady_clock::now();
         int st = bt_render_device(scene, camera, &cfg, &rc, d_frame, args.width, args.height, args.seed, nullptr);
         check(st, "bt_render_device");
@@ -184,6 +193,15 @@ int main(int argc, char **argv) {
         const double delta = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         sum_delta += delta;
         buffer_samples += rc.samples * nn;                 // Buffer::inc_samples, mod.rs:199
+        if (!args.stats_json.empty()) {
+            bt_stats cs{};
+            bt_scene_last_stats(scene, &cs);
+            char row[256];
+            std::snprintf(row, sizeof row, "%s{\"kernel_ms\": %.5f, \"segments\": %llu, \"samples\": %llu, \"pixels\": %llu, \"slices\": %u}",
+                          per_call.empty() ? "" : ", ", cs.kernel_ms, (unsigned long long)cs.segments,
+                          (unsigned long long)cs.samples, (unsigned long long)cs.pixels, cs.slices);
+            per_call += row;
+        }
         if (!args.quiet)
             std::fprintf(stderr, "bendy tracer; samples: %u/%u; delta t: %s\n", buffer_samples, args.samples,
                          fmt_duration(delta / (rc.samples * nn)).c_str());
@@ -196,9 +214,17 @@ int main(int argc, char **argv) {
     std::fprintf(stderr, "%.1f Msamples/s (render calls only)\n",
                  sum_delta > 0 ? (double)n_px * buffer_samples / sum_delta / 1e6 : 0.0);
 
+    if (!args.stats_json.empty()) {
+        FILE *f = std::fopen(args.stats_json.c_str(), "w");
+        if (!f) die("cannot write " + args.stats_json);
+        std::fprintf(f, "{\"width\": %u, \"height\": %u, \"samples_per_call\": %u, \"subsample\": %u, \"calls\": [%s]}\n", args.width,
+                     args.height, args.samples_per_call, args.subsample, per_call.c_str());
+        std::fclose(f);
+    }
+
     // Ctrl+P (main.rs:275-298)
     std::string shot = args.screenshot;
-    {
+    if (!args.no_screenshot) {
         size_t slash = shot.find_last_of('/');
         std::string file = slash == std::string::npos ? shot : shot.substr(slash + 1);
         if (file.find('.') == std::string::npos)           // no extension -> with_file_name("render.png")
@@ -213,12 +239,14 @@ int main(int argc, char **argv) {
             }
         }
     }
-    check(bt_preview_device(d_frame, d_rgba8, args.width, args.height, buffer_samples ? buffer_samples : 1, color_space, nullptr),
-          "bt_preview_device");
-    std::vector<uint8_t> rgba8(n_px * 4);
-    hip_check(hipMemcpy(rgba8.data(), d_rgba8, n_px * 4, hipMemcpyDeviceToHost), "hipMemcpy");
-    check(bt_write_png(shot.c_str(), rgba8.data(), args.width, args.height), "bt_write_png");
-    std::fprintf(stderr, "saved screenshot to %s\n", shot.c_str());
+    if (!args.no_screenshot) {
+        check(bt_preview_device(d_frame, d_rgba8, args.width, args.height, buffer_samples ? buffer_samples : 1, color_space, nullptr),
+              "bt_preview_device");
+        std::vector<uint8_t> rgba8(n_px * 4);
+        hip_check(hipMemcpy(rgba8.data(), d_rgba8, n_px * 4, hipMemcpyDeviceToHost), "hipMemcpy");
+        check(bt_write_png(shot.c_str(), rgba8.data(), args.width, args.height), "bt_write_png");
+        std::fprintf(stderr, "saved screenshot to %s\n", shot.c_str());
+    }
 
     // Ctrl+K (main.rs:299-313)
     if (!args.save_scene.empty()) {
