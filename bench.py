@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Msamples/s of Tracer::render on the GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload C3] [--scaling weak|strong] [--backend nccl|rccl-abi|gloo]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json metric "Msamples/s (pixels x spp / s) at 1080p", config C3):
-scene.json.gz, 1920x1080, Subsample::None, Config = main.rs values.  One "step" is one
-Tracer::render call that adds `samples` rays per pixel to a frame that stays resident in HBM
-(the reference's progressive pattern, main.rs:245-254; step i uses sample_base = i * samples).
-N = 1: samples = 64 (exactly C3).  N > 1 (weak scaling): samples = 64 * N, the 16x16 pixel tiles
-are dealt round-robin to the ranks, each rank renders its tiles into a rank-local shard of
-running sums, one RCCL all-gather (over xGMI) collects the shards and an un-permute kernel
-rebuilds the row-major frame.  Shard sums are rank-local, so step i+1's render does not depend on
-step i's exchange: the all-gather + un-permute of step i run on a second HIP stream underneath
-the render of step i+1.  Everything, including the last exchange, is inside the timed region.
+Workload (BASELINE.json metric "Msamples/s (pixels x spp / s) at 1080p", config C3): scene.json.gz, 1920x1080,
+Subsample::None, Config = main.rs values.  One "step" is one Tracer::render call that adds `samples` rays per pixel
+to a frame that stays resident in HBM (the reference's progressive pattern, main.rs:245-254; step i uses
+sample_base = i * samples).
 
-One JSON line on rank 0, with `roofline` (SURVEY 8(d) byte model, HIP-event kernel time) and,
-at N = 1, `cpu_baseline` (the CPU oracle -- a C port of the reference algorithm, NOT the Rust
-binary -- timed on the host cores on a bounded sample of the same workload).
+N > 1: the 16x16 pixel tiles are dealt round-robin to the ranks, each rank renders its tiles into a rank-local shard
+of running sums, one RCCL all-gather (over xGMI) collects the shards and an un-permute kernel rebuilds the row-major
+frame.  Shard sums are rank-local, so step i+1's render does not depend on step i's exchange: the all-gather +
+un-permute of step i run on a second HIP stream underneath the render of step i+1.  Everything, including the last
+exchange, is inside the timed region.
+  --scaling weak   (default) samples per step = 64 * N: fixed work per GPU.
+  --scaling strong samples per step stay what the workload names (so `--workload C5 --gpus 8 --scaling strong` IS
+                   BASELINE configs[4]: 3840x2160x256 spp sharded over 8 GPUs); a second timed pass gathers only once,
+                   after the last step ("the final framebuffer"), and is reported as `final_gather_only`.
+  --backend nccl   torch.distributed's RCCL; rccl-abi = the library's own bt_comm_* entry points (the exchange a
+                   non-Python host would call); gloo = rehearsal on a box with fewer GPUs than ranks.
+
+One JSON line on rank 0.  `roofline` (N = 1): the kernel is VALU-bound, so `achieved` / `peak` are wave64 VALU
+instructions per SIMD-cycle (peak 0.5: MI355X_MICROARCH.md, 2 cycles per instruction on a SIMD-32), with the HBM
+bytes (`traffic`) and every counter MEASURED IN THIS RUN by rocprofv3 --pmc passes over the same workload
+(tools/pmc_collect.py; separate passes, FETCH_SIZE doubled per the guide) -- unless rocprofv3 is unavailable, then the
+committed summary profiles/pmc_live.json is quoted and flagged `stale` when its source hash differs from this tree.
+`cpu_baseline` (N = 1): the CPU oracle -- a C port of the reference algorithm, NOT the Rust binary -- timed on the host
+cores on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -28,6 +38,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 # the host driver of this pool only supports dmabuf IPC: without it RCCL fails with hipIpcGetMemHandle: invalid argument
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
@@ -38,11 +49,14 @@ WORKLOADS = {
     "C4": ("volume", 1920, 1080, 64),
     "C5": ("scene", 3840, 2160, 256),
     "cornell1080": ("cornell", 1920, 1080, 64),
+    "cloud1080": ("cloud", 1920, 1080, 64),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+VALU_PEAK = 0.5                # wave64 VALU instructions per SIMD-cycle (2 cycles each on a SIMD-32)
 BYTES_PER_SEGMENT = 128        # 64-byte SoA ray state read + written once per segment
 BYTES_PER_PIXEL = 16           # RGBA32F written once per pixel per render
 SEED = 0x5EED
+PMC_CACHE = os.path.join(ROOT, "profiles", "pmc_live.json")
 
 
 def cpu_baseline(scene_name, w, h, budget_s=15.0):
@@ -76,8 +90,8 @@ def cpu_baseline(scene_name, w, h, budget_s=15.0):
     n = w * h * spp
     return {
         "value": round(n * passes / t_fine / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": f"{scene_name}.json.gz {w}x{h}: {passes} passes of {spp} spp (C oracle, recursive form, -O2, "
-                  f"{cores} threads, 32x32 dynamic tiles; {t_fine:.1f} s)",
+        "sample": f"{scene_name}.json.gz {w}x{h}: {passes} passes of {spp} spp (C oracle, recursive form, gcc -O3 "
+                  f"-ffp-contract=off, {cores} threads, 32x32 dynamic tiles; {t_fine:.1f} s)",
         "reference_tiling_8x4_value": round(n / t_ref / 1e6, 3),
     }
 
@@ -106,23 +120,28 @@ def parity_figure(b, torch, scene_name, w=240, h=135, spp=16):
             "max_abs_delta_mean_vs_cpu_recursive_form": float(np.abs(got[..., :3] - rec[..., :3]).max() / spp),
             "bit_identical_to_cpu_iterative_form": bool(np.array_equal(got, it)),
             "note": "CPU ref = this repo's C restatement of the reference algorithm (the Rust binary cannot be built here and "
-                    "seeds from OS entropy); full-size parity is in tests/test_gpu_parity.py"}
+                    "seeds from OS entropy); whole frames at the BASELINE sizes are compared in tests/test_gpu_parity.py"}
 
 
-def load_pmc_traffic(workload):
-    """HBM bytes per launch from a committed rocprofv3 --pmc run (profiles/pmc_traffic.json)."""
+def measure_pmc(workload):
+    """rocprofv3 --pmc passes over this workload, run as child processes BEFORE this process touches the GPU
+    (tools/pmc_collect.py; the profiled program is the C++ CLI over the same library).  Falls back to the committed
+    summary, flagged with whether it was taken on this source tree."""
+    import pmc_collect
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload)
-    except Exception:
-        return None
-
-
-def load_pmc_valu(workload):
-    """VALU counters of the same committed PMC run: what actually bounds the kernel."""
+        res = pmc_collect.collect(workload, calls=4, passes=("fetch", "write", "sq", "classes"))
+        res["measured"] = "in this run (rocprofv3 --pmc, separate passes: FETCH_SIZE | WRITE_SIZE | SQ | VALU classes)"
+        res["stale"] = False
+        return res
+    except Exception as e:                                     # no rocprofv3, no counters for this user, ...
+        why = str(e)[:300]
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload + "_valu")
+        res = json.load(open(PMC_CACHE))[workload]
+        res["measured"] = f"profiles/pmc_live.json (live measurement unavailable: {why})"
+        res["stale"] = res.get("source_sha") != pmc_collect.source_hash()
+        return res
     except Exception:
-        return None
+        return {"measured": f"unavailable: {why}", "stale": None, "mean_per_launch": {}, "derived": {}}
 
 
 def lens_extension_rate(b, torch, scene_name, w, h, spp=64, steps=2):
@@ -157,19 +176,31 @@ class ShardExchange:
         self.shard = b.new_shard(w, h, world)
         self.gathered = torch.empty(world * self.shard.numel(), dtype=torch.float32, device="cuda")
         self.frame = b.Buffer.new(w, h)
+        self.comm = None
+        if backend == "rccl-abi":
+            # the library's own communicator (include/bendy_hip.h bt_comm_*): rank 0's unique id reaches the others
+            # through the process group that exists anyway for the barrier
+            uid = [b.Comm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            self.comm = b.Comm(rank, world, uid[0])
         if overlap:
             self.staging = [torch.empty_like(self.shard) for _ in range(2)]
-            self.comm = torch.cuda.Stream()
+            self.comm_stream = torch.cuda.Stream()
             self.ev_ready = [torch.cuda.Event() for _ in range(2)]
             self.ev_free = [torch.cuda.Event() for _ in range(2)]
 
-    def _gather(self, src):
+    def _gather_unshard(self, src, frame):
+        if self.backend == "rccl-abi":
+            self.comm.exchange(src, self.gathered, frame)                # ncclAllGather + un-permute behind the C ABI
+            return
         if self.backend == "nccl":
             self.dist.all_gather_into_tensor(self.gathered, src)        # RCCL over xGMI
         else:                                                            # gloo rehearsal: staged through the host
             host = self.torch.empty(self.gathered.numel(), dtype=self.torch.float32)
             self.dist.all_gather_into_tensor(host, src.cpu())
             self.gathered.copy_(host)
+        self.b.unshard(self.gathered, frame, self.world)
 
     def exchange(self, i, shard=None, frame=None):
         """Collects every rank's shard of step i into `frame`; with overlap it runs on the comm stream."""
@@ -177,23 +208,25 @@ class ShardExchange:
         shard = self.shard if shard is None else shard
         frame = self.frame if frame is None else frame
         if not self.overlap:
-            self._gather(shard)
-            self.b.unshard(self.gathered, frame, self.world)
+            self._gather_unshard(shard, frame)
             return
         s = i & 1
         cur = torch.cuda.current_stream()
         cur.wait_event(self.ev_free[s])             # staging[s] was last read by the exchange two steps back
         self.staging[s].copy_(shard)                 # snapshot: the next render keeps adding into `shard`
         self.ev_ready[s].record(cur)
-        with torch.cuda.stream(self.comm):
-            self.comm.wait_event(self.ev_ready[s])
-            self._gather(self.staging[s])
-            self.b.unshard(self.gathered, frame, self.world)
-            self.ev_free[s].record(self.comm)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self.ev_ready[s])
+            self._gather_unshard(self.staging[s], frame)
+            self.ev_free[s].record(self.comm_stream)
 
     def drain(self):
         if self.overlap:
-            self.torch.cuda.current_stream().wait_stream(self.comm)
+            self.torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def reset(self):
+        self.shard.zero_()
+        self.shard.view(-1, 4)[:, 3] = 1.0
 
 
 def main():
@@ -202,21 +235,19 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (quote the committed summary)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (shards staged through the host)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "rccl-abi", "gloo"],
+                    help="rccl-abi = the library's bt_comm_* entry points; gloo = rehearsal of the N>1 path on a box with "
+                         "fewer GPUs than ranks (shards staged through the host)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-overlap", action="store_true", help="run the frame exchange on the render stream")
     ap.add_argument("--verify", action="store_true", help="compare the gathered frame with a one-rank render of the same steps")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (process group, shard, all-gather, un-permute) even with one rank")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-
-    import bendy_tracer_amd as b
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -225,22 +256,42 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    dist_path = world > 1 or args.force_dist          # `dist_path` replaces `world > 1` below
+
+    # counters first: child processes under rocprofv3, while this process has not initialised the GPU yet
+    pmc = None
+    if world == 1 and rank == 0 and not args.force_dist:
+        if args.no_pmc:
+            try:
+                import pmc_collect
+                pmc = json.load(open(PMC_CACHE))[args.workload]
+                pmc["measured"] = "profiles/pmc_live.json (--no-pmc)"
+                pmc["stale"] = pmc.get("source_sha") != pmc_collect.source_hash()
+            except Exception:
+                pmc = None
+        else:
+            pmc = measure_pmc(args.workload)
+
+    import torch
+    import torch.distributed as dist
+
+    import bendy_tracer_amd as b
+
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist_path = world > 1 or args.force_dist          # `dist_path` replaces `world > 1` below
     if dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
+        if args.backend == "gloo":
             dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     scene_name, w, h, base_spp = WORKLOADS[args.workload]
-    spp = base_spp * world                                  # weak scaling: fixed work per GPU
+    spp = base_spp * world if args.scaling == "weak" else base_spp      # weak: fixed work per GPU; strong: fixed total
     scene = b.Scene.load(os.path.join(ROOT, "scenes", f"{scene_name}.json.gz"))
     cam = scene.find_by_tag("camera")
     scene.set_camera_aspect(cam, w / h)                     # main.rs:218-223
@@ -252,12 +303,13 @@ def main():
         ex = ShardExchange(b, torch, dist, w, h, rank, world, args.backend, overlap=not args.no_overlap)
         frame = ex.frame
 
-    def step(i):
+    def step(i, exchange=True):
         if not dist_path:
             tracer.render(scene, cam, rc, frame, seed=SEED, sample_base=i * spp)
         else:
             tracer.render_shard(scene, cam, rc, ex.shard, w, h, rank, world, seed=SEED, sample_base=i * spp)
-            ex.exchange(i)
+            if exchange:
+                ex.exchange(i)
 
     def sync():
         if dist_path:
@@ -267,22 +319,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(first, exchange_every_step=True):
+        """K steps bracketed by barrier + synchronize on both sides; -> (seconds, max over ranks), per-step stream ms."""
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ev[i][0].record()                               # same stream the render kernel is launched on
+            step(first + i, exchange=exchange_every_step or i == args.steps - 1)
+            ev[i][1].record()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if dist_path:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend != "gloo" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, [a.elapsed_time(c) for a, c in ev]
+
     for i in range(args.warmup):
         step(i)
-    sync()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()                                   # same stream the render kernel is launched on
-        step(args.warmup + i)
-        ev[i][1].record()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist_path:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    step_ms = [a.elapsed_time(c) for a, c in ev]
+    elapsed, step_ms = timed(args.warmup)
 
     verified = None
     if args.verify:
@@ -294,6 +350,13 @@ def main():
         torch.cuda.synchronize()
         verified = bool(torch.equal(frame.data, ref.data))
 
+    final_only = None
+    if dist_path and args.scaling == "strong":
+        # second timed pass: the shards keep accumulating, ONE exchange after the last step (the final framebuffer)
+        e2, _ = timed(args.warmup + args.steps, exchange_every_step=False)
+        final_only = {"value": round(w * h * spp * args.steps / e2 / 1e6, 2), "unit": "Msamples/s",
+                      "ms_per_step": round(e2 / args.steps * 1e3, 4), "exchanges": 1}
+
     # segment counts and the library's own HIP-event kernel times: replay the same renders, untimed
     kernel_ms, segments = [], []
     for i in range(args.steps):
@@ -304,46 +367,65 @@ def main():
         st = scene.last_stats()
         kernel_ms.append(st.kernel_ms)
         segments.append(st.segments)
-    my_pixels = scene.last_stats().pixels
+    last = scene.last_stats()
+    my_pixels = last.pixels
 
     total_samples = w * h * spp * args.steps
     value = total_samples / elapsed / 1e6
     out = {
         "metric": "Msamples/s (pixels x spp / s) at 1080p" if h == 1080 else "Msamples/s (pixels x spp / s)",
         "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {scene_name}.json.gz {w}x{h}x{spp}spp Subsample::None, Config=main.rs "
                                f"(max_bounces 8, max_volume_bounces 32, clip 0.01..1000, volume_step 0.1, Output::Full), "
                                f"flat space (the reference has no lens code), seed 0x5EED",
                    "samples_per_step": w * h * spp,
-                   "parallelism": (f"tiles{world}" + ("" if args.no_overlap else "+overlapped-allgather")) if dist_path else "single"},
+                   "parallelism": (f"tiles{world}:{args.backend}" + ("" if args.no_overlap else "+overlapped-allgather")) if dist_path else "single"},
     }
     if rank == 0:
         k_ms = statistics.mean(kernel_ms)
         seg = statistics.mean(segments)
+        # template arguments <OUTPUT, LENS, SLICED (work queue), RECTS, VOLS>, as rocprofv3 prints them
+        kernel_name = "bt_render_kernel<0, false, %s, %s, %s>" % (
+            "true" if spp >= 2 else "false",
+            *{"scene": ("false", "false"), "volume": ("false", "true"), "cloud": ("false", "true")}.get(scene_name, ("true", "false")))
+        roof = {"bound": "valu", "unit": "wave64 VALU instructions per SIMD-cycle", "peak": VALU_PEAK, "achieved": None,
+                "frac": None, "traffic": None, "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "slices": last.slices,
+                "launches_per_step": last.launches, "scratch_bytes": last.scratch_bytes,
+                "render_stream_ms_per_step_timed_region": round(statistics.mean(step_ms), 4),
+                "segments_per_launch": int(seg), "segments_per_sample": round(seg / (my_pixels * spp), 4)}
+        if pmc and pmc.get("derived"):
+            d, m = pmc["derived"], pmc.get("mean_per_launch", {})
+            roof["achieved"] = round(d["valu_per_simd_cycle"], 4) if "valu_per_simd_cycle" in d else None
+            roof["frac"] = round(d["valu_issue_frac"], 4) if "valu_issue_frac" in d else None
+            roof["lane_weighted_frac"] = round(d["valu_lane_weighted_frac"], 4) if "valu_lane_weighted_frac" in d else None
+            roof["issue_cost_weighted_frac"] = round(d["valu_issue_weighted_frac"], 4) if "valu_issue_weighted_frac" in d else None
+            roof["lanes_active_per_valu_inst"] = round(d["lanes_active"], 4) if "lanes_active" in d else None
+            roof["scalar_insts_per_cu_cycle"] = round(d["scalar_per_cu_cycle"], 4) if "scalar_per_cu_cycle" in d else None
+            if "hbm_bytes" in d:
+                roof["traffic"] = int(d["hbm_bytes"])
+                roof["hbm_measured_frac"] = round(d["hbm_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roof["valu_wave_insts_per_launch"] = int(m["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in m else None
+            roof["valu_class_counts"] = d.get("valu_class_counts")
+            roof["pmc"] = {"measured": pmc.get("measured"), "source_sha": pmc.get("source_sha"), "stale": pmc.get("stale"),
+                           "commit": pmc.get("commit"), "kernel_cycles": round(d["kernel_cycles"]) if "kernel_cycles" in d else None,
+                           "kernel_ms_under_profiler": pmc.get("cli", {}).get("kernel_ms_under_profiler")}
+        # SURVEY 8(d)'s byte model, kept as a labelled non-headline figure: a wavefront formulation would move these bytes,
+        # the shipped register-resident kernel does not
         alg_bytes = BYTES_PER_SEGMENT * seg + BYTES_PER_PIXEL * my_pixels
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        out["roofline"] = {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(args.workload) if world == 1 else None,
-            # template arguments <OUTPUT, LENS, SLICED (work queue), RECTS, VOLS>, as rocprofv3 prints them
-            "kernel": "bt_render_kernel<0, false, %s, %s, %s>" % (
-                "true" if spp >= 2 else "false", *{"scene": ("false", "false"), "volume": ("false", "true")}.get(scene_name, ("true", "false"))),
-            "kernel_ms": round(k_ms, 4), "slices": scene.last_stats().slices,
-            "render_stream_ms_per_step_timed_region": round(statistics.mean(step_ms), 4),
-            "valu_pmc": load_pmc_valu(args.workload) if world == 1 else None,
-            "segments_per_launch": int(seg), "segments_per_sample": round(seg / (my_pixels * spp), 4),
-            "algorithmic_bytes_per_launch": int(alg_bytes),
-            "note": "byte model of SURVEY 8(d): 128 B per path segment (wavefront SoA ray state) + 16 B per pixel; "
-                    "the shipped kernel keeps ray state in registers, so real HBM traffic (`traffic`: 16 B per sample "
-                    "parked and read back once + 32 B/pixel of frame) is ~15% of the model and the kernel is "
-                    "VALU-bound, not HBM-bound (DESIGN.md 'Roofline'); frac > 1 therefore only says that the kernel is "
-                    "faster than any kernel that really moved the model's traffic could be",
-        }
+        roof["model"] = {"bytes_per_launch": int(alg_bytes), "model_frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "SURVEY 8(d) wavefront byte model (128 B per path segment + 16 B per pixel) over kernel time / "
+                                 "8 TB/s; NOT traffic of this kernel, which keeps ray state in registers -- see `traffic`"}
+        roof["note"] = ("VALU-bound path tracer: frac = measured wave64 VALU instructions per SIMD-cycle / 0.5; "
+                        "issue_cost_weighted_frac weights the PMC opcode classes with the issue cycles measured by "
+                        "tools/valu_microbench.hip (profiles/valu_issue_costs.json); hbm_measured_frac = PMC bytes / kernel time / 8 TB/s")
+        out["roofline"] = roof
         if verified is not None:
             out["verified_vs_single_rank"] = verified
-        if world == 1 and args.workload == "C3":
+        if final_only is not None:
+            out["final_gather_only"] = final_only
+        if world == 1 and args.workload == "C3" and not args.force_dist:
             out["lens_extension"] = lens_extension_rate(b, torch, scene_name, w, h)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_name, w, h, args.cpu_budget)
@@ -351,6 +433,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist_path:
         dist.barrier()
+        if getattr(ex, "comm", None) is not None:
+            ex.comm.close()
         dist.destroy_process_group()
 
 

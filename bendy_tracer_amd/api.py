@@ -122,7 +122,13 @@ class _CRenderConfig(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("pixels", C.c_uint64), ("kernel_ms", C.c_float),
-                ("lens_steps", C.c_uint64), ("slices", C.c_uint32), ("reserved", C.c_uint32)]
+                ("lens_steps", C.c_uint64), ("slices", C.c_uint32), ("launches", C.c_uint32),
+                ("scratch_bytes", C.c_uint64), ("parked_bytes", C.c_uint64)]
+
+
+class _CTuning(C.Structure):  # include/bendy_hip.h `bt_tuning`
+    _fields_ = [("slices", C.c_uint32), ("tiles_per_wg", C.c_uint32), ("queue", C.c_int32), ("phase_vote", C.c_int32),
+                ("kernel_variant", C.c_int32), ("park", C.c_int32), ("scratch_cap_bytes", C.c_uint64)]
 
 
 class _CLens(C.Structure):
@@ -135,7 +141,8 @@ EXPORTS = [
     "bt_scene_from_json", "bt_scene_free", "bt_scene_find_by_tag", "bt_scene_set_camera_aspect", "bt_scene_set_lens",
     "bt_scene_object_count", "bt_scene_data_count", "bt_scene_export_prims", "bt_render", "bt_render_device",
     "bt_shard_floats", "bt_render_shard_device", "bt_unshard_device", "bt_preview_device", "bt_preview",
-    "bt_scene_last_stats", "bt_set_kernel_variant", "bt_scene_default", "bt_scene_to_json", "bt_scene_save", "bt_write_png",
+    "bt_comm_unique_id", "bt_comm_init", "bt_comm_free", "bt_comm_rank", "bt_comm_world", "bt_allgather_shards_device",
+    "bt_exchange_frame_device", "bt_scene_last_stats", "bt_tuning_default", "bt_scene_set_tuning", "bt_scene_get_tuning", "bt_scene_default", "bt_scene_to_json", "bt_scene_save", "bt_write_png",
 ]
 
 
@@ -185,6 +192,17 @@ def _load():
     L.bt_preview_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp]
     L.bt_preview.argtypes = [fp, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32]
     L.bt_scene_last_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.bt_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
+    L.bt_comm_init.restype = vp
+    L.bt_comm_init.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.bt_comm_free.argtypes = [vp]
+    L.bt_comm_rank.argtypes = [vp]
+    L.bt_comm_world.argtypes = [vp]
+    L.bt_allgather_shards_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.bt_exchange_frame_device.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.bt_tuning_default.argtypes = [C.POINTER(_CTuning)]
+    L.bt_scene_set_tuning.argtypes = [vp, C.POINTER(_CTuning)]
+    L.bt_scene_get_tuning.argtypes = [vp, C.POINTER(_CTuning)]
     return L
 
 
@@ -286,6 +304,43 @@ class Scene:
         out = np.zeros(n, dtype=np.float32)
         _check(lib.bt_scene_export_prims(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), n))
         return out.reshape(-1, 36)
+
+    KERNEL_VARIANTS = {"default": 0, "lanes": 1, "sorted": 2}
+
+    def set_tuning(self, **knobs):
+        """bt_scene_set_tuning: pins launch-shape knobs of this handle (tests and A/B tools; none of them changes a
+        pixel).  Keywords = fields of `bt_tuning` (slices, tiles_per_wg, queue, phase_vote, kernel_variant -- a name
+        or a number --, park, scratch_cap_bytes); fields not named keep their current value; no keywords = defaults."""
+        t = _CTuning()
+        if not knobs:
+            _check(lib.bt_scene_set_tuning(self._h, None))
+            return
+        _check(lib.bt_scene_get_tuning(self._h, C.byref(t)))
+        for k, v in knobs.items():
+            if k == "kernel_variant" and isinstance(v, str):
+                v = self.KERNEL_VARIANTS[v]
+            if not hasattr(t, k):
+                raise TypeError(f"bt_tuning has no field {k!r}")
+            setattr(t, k, int(v))
+        _check(lib.bt_scene_set_tuning(self._h, C.byref(t)))
+
+    def tuning(self) -> dict:
+        t = _CTuning()
+        _check(lib.bt_scene_get_tuning(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _CTuning._fields_}
+
+    def tuning_from_env(self, environ=None):
+        """Developer convenience for tools/ and tests/: BT_SLICES, BT_TILES_PER_WG, BT_QUEUE, BT_PHASE_VOTE, BT_KERNEL,
+        BT_PARK, BT_SCRATCH_CAP -> set_tuning().  The library itself never reads the environment."""
+        env = os.environ if environ is None else environ
+        names = {"BT_SLICES": "slices", "BT_TILES_PER_WG": "tiles_per_wg", "BT_QUEUE": "queue",
+                 "BT_PHASE_VOTE": "phase_vote", "BT_PARK": "park", "BT_SCRATCH_CAP": "scratch_cap_bytes"}
+        knobs = {f: int(env[e]) for e, f in names.items() if env.get(e) not in (None, "", "-")}
+        if env.get("BT_KERNEL") in self.KERNEL_VARIANTS:
+            knobs["kernel_variant"] = env["BT_KERNEL"]
+        if knobs:
+            self.set_tuning(**knobs)
+        return knobs
 
     def last_stats(self) -> Stats:
         st = Stats()
@@ -395,7 +450,8 @@ class Tracer:
         seed = self.DEFAULT_SEED if seed is None else seed
         nn = config.subsample.subpixel_count()
         if sample_base is None:
-            sample_base = buffer.samples // nn
+            # the next unused sample index: ceil, so that a change of `subsample` between calls never replays indices
+            sample_base = (buffer.samples + nn - 1) // nn
         c, r = _c_configs(self.config, config, sample_base)
         if buffer.device == "cpu":
             rc = lib.bt_render(scene._h, camera, C.byref(c), C.byref(r),
@@ -421,9 +477,45 @@ class Tracer:
         return Status(_check(rc))
 
 
-def set_kernel_variant(name):
-    """"default" | "lanes" | "sorted": which of the two bit-identical render kernels runs (A/B measurements)."""
-    _check(lib.bt_set_kernel_variant({"default": 0, "lanes": 1, "sorted": 2}[name]))
+class Comm:
+    """`bt_comm` (include/bendy_hip.h): the RCCL communicator of the frame exchange, behind the C ABI -- what a host
+    without an RCCL binding of its own calls.  One process per GPU; `unique_id()` on rank 0, its 128 bytes handed to
+    the other ranks by any host-side channel, then `Comm(rank, world, uid)` on every rank (collective)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        _check(lib.bt_comm_unique_id(buf, Comm.ID_BYTES))
+        return buf.raw
+
+    def __init__(self, rank, world, uid: bytes):
+        assert len(uid) == self.ID_BYTES
+        h = lib.bt_comm_init(rank, world, uid, len(uid))
+        if not h:
+            raise BendyError(lib.bt_last_error_code(), lib.bt_last_error().decode("utf-8", "replace"))
+        self._h = C.c_void_p(h)
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.bt_comm_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def allgather(self, shard, gathered, width, height):
+        import torch
+        assert gathered.numel() == self.world * shard.numel() == self.world * shard_floats(width, height, self.world)
+        _check(lib.bt_allgather_shards_device(self._h, shard.data_ptr(), gathered.data_ptr(), width, height,
+                                              torch.cuda.current_stream().cuda_stream))
+
+    def exchange(self, shard, gathered, buffer: "Buffer"):
+        """All-gather + un-permute: every rank's `buffer` then holds the whole frame of running sums."""
+        import torch
+        _check(lib.bt_exchange_frame_device(self._h, shard.data_ptr(), gathered.data_ptr(), buffer.data.data_ptr(),
+                                            buffer.width, buffer.height, torch.cuda.current_stream().cuda_stream))
 
 
 def write_png(path, rgba8):

@@ -32,8 +32,8 @@ static_assert(BT_TILE == BT_TILE_DIM, "public and device tile sizes must agree")
 namespace {
 
 thread_local std::string g_error;
-int g_kernel_variant = 0;          // bt_set_kernel_variant: 0 = default (BT_KERNEL_LANES unless $BT_KERNEL says otherwise)
 thread_local int g_error_code = 0;
+constexpr uint64_t kDefaultScratchCap = 2ull << 30;   // parked sample values per launch; deeper renders are split
 int set_error(int code, const std::string &msg) {
     g_error = msg;
     g_error_code = code;
@@ -82,18 +82,32 @@ struct bt_scene {
     unsigned long long *d_counters = nullptr;
     float *d_scratch = nullptr;    // parked sample values of sliced renders
     size_t scratch_bytes = 0;
+    float *d_host_frame = nullptr; // device copy of the caller's host buffer (bt_render), kept between calls
+    size_t host_frame_bytes = 0;
+    int n_cu = 0;                  // hipDeviceProp_t::multiProcessorCount of `device`
+    bt_tuning tuning{};            // bt_scene_set_tuning; zero / negative fields = automatic
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bt_stats last{};
     bool lens_on = false;          // lens extension (not in the reference), bt_scene_set_lens
     bt_lens lens{};
     bool stats_pending = false;
 
-    ~bt_scene() {
+    bt_scene() { bt_tuning_default(&tuning); }
+    // everything that lives on `device` besides the scene tables (which upload() replaces)
+    void release_device_state() {
         if (d_counters) (void)hipFree(d_counters);
         if (d_scratch) (void)hipFree(d_scratch);
+        if (d_host_frame) (void)hipFree(d_host_frame);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
+        d_counters = nullptr;
+        d_scratch = nullptr;
+        d_host_frame = nullptr;
+        scratch_bytes = host_frame_bytes = 0;
+        ev_start = ev_stop = nullptr;
+        stats_pending = false;
     }
+    ~bt_scene() { release_device_state(); }
 };
 
 namespace {
@@ -123,6 +137,18 @@ int ensure_device(bt_scene *s) {
     int dev = -1;
     BT_HIP(hipGetDevice(&dev));
     if (s->device_valid && s->device == dev) return 0;
+    if (s->device >= 0 && s->device != dev) {
+        // the handle moves to another GPU: counters, scratch, the cached host frame and the events belong to the old
+        // one (a kernel on `dev` must not write into them) -- free them there and start afresh here
+        (void)hipSetDevice(s->device);
+        s->release_device_state();
+        BT_HIP(hipSetDevice(dev));
+    }
+    {
+        hipDeviceProp_t prop;
+        BT_HIP(hipGetDeviceProperties(&prop, dev));
+        s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     BT_HIP(s->d_prims.upload(s->flat.prims));
     BT_HIP(s->d_materials.upload(s->flat.materials));
     BT_HIP(s->d_volumes.upload(s->flat.volumes));
@@ -331,36 +357,38 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     // whose paths differ far more in length; down to 4 as well when the launch has too few pixels to fill the GPU).
     // A render whose scratch would exceed the cap is issued as several launches over consecutive sample ranges
     // (k launches of m samples == one launch of k * m samples).  One ray per pixel, or no memory for the scratch ->
-    // the lanes kernel, which needs none.  Environment knobs are for A/B measurements and tests only.
+    // the lanes kernel, which needs none.  bt_tuning (bt_scene_set_tuning) pins any of these for tests and A/B tools.
+    const bt_tuning &tune = s->tuning;
     const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
     const uint64_t px_launch = (uint64_t)grid * BT_TILE_DIM * BT_TILE_DIM;
     uint32_t chunk = (uint32_t)P.samples;                         // samples per launch
     P.slices = 1;
     P.scratch = nullptr;
+    // the launch should hold >= 4 x 20 waves per CU (tuned on the MI355X's 256 CUs as "4 * 5120 waves", round 1d)
+    const uint64_t wave_slots = (uint64_t)s->n_cu * 20;
     {
-        uint64_t cap = 8ull << 30;
-        if (const char *e = getenv("BT_SCRATCH_CAP")) cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
-        const char *forced_s = getenv("BT_SLICES");                // 1, 2, 4, 8, 16, 32
+        const uint64_t cap = tune.scratch_cap_bytes ? tune.scratch_cap_bytes : kDefaultScratchCap;
         auto pick = [&](uint64_t T) -> uint32_t {
-            if (forced_s) {
-                const int v = atoi(forced_s);
-                if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) return (uint32_t)v;
-            }
+            if (tune.slices) return tune.slices;
             uint32_t S = 1;
             const uint64_t per_lane = P.lens_on ? 4 : 16;
             while (S < 32 && T / (2 * S) >= per_lane) S *= 2;
             const uint64_t waves = (uint64_t)grid * 4;
-            while (S < 16 && waves * S < 4 * 5120 && T / (2 * S) >= 4) S *= 2;
+            while (S < 16 && waves * S < 4 * wave_slots && T / (2 * S) >= 4) S *= 2;
             return S;
         };
         bool queue = (uint64_t)chunk * nn >= 2;
-        if (const char *e = getenv("BT_QUEUE")) queue = atoi(e) != 0;
+        if (tune.queue >= 0) queue = tune.queue != 0;
         if (queue) {
             const uint64_t per_sample = px_launch * nn * 4 * sizeof(float);
             if (per_sample * chunk > cap) chunk = (uint32_t)std::max<uint64_t>(1, cap / per_sample);
             const uint64_t need = per_sample * chunk;
-            if (s->scratch_bytes < need) {
-                if (s->d_scratch) (void)hipFree(s->d_scratch);
+            // grow when too small; give the memory back when this render needs less than a quarter of what is held
+            if (s->scratch_bytes < need || s->scratch_bytes / 4 > need) {
+                if (s->d_scratch) {
+                    BT_HIP(hipStreamSynchronize(stream));      // an earlier launch on this stream may still read it
+                    (void)hipFree(s->d_scratch);
+                }
                 s->d_scratch = nullptr;
                 s->scratch_bytes = 0;
                 if (hipMalloc((void **)&s->d_scratch, need) == hipSuccess) {
@@ -382,12 +410,9 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             const uint64_t T = (uint64_t)chunk * nn;
             uint32_t tpw = 1;
             while (P.slices == 1 && !P.any_rects && !P.any_volumes && tpw < 4 && 256ull * (2 * tpw) * T <= 4096 &&
-                   grid / (2 * tpw) >= 3584)
+                   (uint64_t)grid / (2 * tpw) >= 2 * (uint64_t)s->n_cu * 7)
                 tpw *= 2;
-            if (const char *e = getenv("BT_TILES_PER_WG")) {
-                const int v = atoi(e);
-                if (P.slices == 1 && (v == 1 || v == 2 || v == 4)) tpw = (uint32_t)v;
-            }
+            if (tune.tiles_per_wg && P.slices == 1) tpw = tune.tiles_per_wg;
             P.tiles_per_wg = (int32_t)tpw;
         } else {
             chunk = (uint32_t)P.samples;
@@ -399,20 +424,15 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
                                                  " bytes) exceed the 160 KB of LDS of a gfx950 CU");
     // longest wait in iterations (0 = no voting); measured best: 3 on scene.json, 4 on the volume scenes
     // (profiles/r01f/ab_phase_vote.log, profiles/r01g/ab_vote_both.log)
-    P.phase_vote = P.any_volumes ? 4 : 3;
-    if (const char *e = getenv("BT_PHASE_VOTE")) P.phase_vote = atoi(e);      // A/B knob
+    P.phase_vote = tune.phase_vote >= 0 ? tune.phase_vote : (P.any_volumes ? 4 : 3);
+    uint32_t launches = 0;
     BT_HIP(hipMemsetAsync(s->d_counters, 0, BT_N_COUNTERS * sizeof(unsigned long long), stream));
     BT_HIP(hipEventRecord(s->ev_start, stream));
     // Two bit-identical kernels: the regrouping one (bt_kernels_sorted.hip, path state in LDS, lanes
     // re-sorted by event kind every iteration) and the lane-owns-pixel one (bt_kernels.hip).  The
     // sorted kernel packs bounce counters into 8 bits and needs ~25 KB of LDS per workgroup on top
-    // of the scene tables; BT_KERNEL=lanes|sorted overrides the choice (A/B runs).
-    static const int env_variant = [] {
-        const char *e = getenv("BT_KERNEL");
-        if (!e) return 0;
-        return std::strcmp(e, "lanes") == 0 ? BT_KERNEL_LANES : (std::strcmp(e, "sorted") == 0 ? BT_KERNEL_SORTED : 0);
-    }();
-    const int variant = g_kernel_variant ? g_kernel_variant : env_variant;
+    // of the scene tables; bt_tuning.kernel_variant selects it per handle (A/B runs).
+    const int variant = tune.kernel_variant;
     const bool can_sort = P.max_bounces < 250 && P.max_volume_bounces < 250 &&
                           s->flat.lds_bytes() + bt_sorted_state_bytes(output) <= 64 * 1024;
     const bool use_sorted = can_sort && variant == BT_KERNEL_SORTED && !P.lens_on;   // the lens lives in the lanes kernel
@@ -420,12 +440,14 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         P.slices = 1;
         P.scratch = nullptr;
         BT_HIP(bt_launch_render_sorted(&P, output, grid, s->flat.lds_bytes(), stream));
+        launches = 1;
     } else {
         const uint32_t all = (uint32_t)P.samples, base = P.sample_base;
         for (uint32_t done = 0; done < all; done += chunk) {
             P.samples = (int32_t)std::min(chunk, all - done);
             P.sample_base = base + done;
             BT_HIP(bt_launch_render(&P, output, grid, s->flat.lds_bytes(), stream));
+            launches += 1;
         }
         P.samples = (int32_t)all;
         P.sample_base = base;
@@ -445,6 +467,9 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     s->last.segments = 0;
     s->last.kernel_ms = 0.0f;
     s->last.slices = (uint32_t)P.slices;
+    s->last.launches = launches;
+    s->last.scratch_bytes = s->scratch_bytes;
+    s->last.parked_bytes = P.scratch ? s->last.samples * 4 * sizeof(float) : 0;
     s->stats_pending = true;
     return BT_IN_PROGRESS;                                             // mod.rs:201
 }
@@ -472,14 +497,42 @@ void bt_render_config_default(bt_render_config *r) {
 }
 
 const char *bt_last_error(void) { return g_error.c_str(); }
+int bt_set_error_internal(int code, const char *msg) { return set_error(code, msg ? msg : ""); }   // for bt_comm.cpp; not in the header
 int bt_last_error_code(void) { return g_error_code; }
 
-int bt_set_kernel_variant(int variant) {
-    if (variant != BT_KERNEL_DEFAULT && variant != BT_KERNEL_LANES && variant != BT_KERNEL_SORTED)
+void bt_tuning_default(bt_tuning *t) {
+    if (!t) return;
+    std::memset(t, 0, sizeof *t);
+    t->queue = -1;
+    t->phase_vote = -1;
+    t->park = -1;
+}
+
+int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
+    if (!scene) return set_error(BT_ERR_INVALID_ARG, "null scene");
+    if (!t) {
+        bt_tuning_default(&scene->tuning);
+        return 0;
+    }
+    const uint32_t S = t->slices, W = t->tiles_per_wg;
+    if (!(S == 0 || S == 1 || S == 2 || S == 4 || S == 8 || S == 16 || S == 32))
+        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.slices must be 0 (auto), 1, 2, 4, 8, 16 or 32");
+    if (!(W == 0 || W == 1 || W == 2 || W == 4))
+        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.tiles_per_wg must be 0 (auto), 1, 2 or 4");
+    if (t->kernel_variant != BT_KERNEL_DEFAULT && t->kernel_variant != BT_KERNEL_LANES && t->kernel_variant != BT_KERNEL_SORTED)
         return set_error(BT_ERR_INVALID_ARG, "unknown kernel variant");
-    g_kernel_variant = variant;
+    if (t->queue < -1 || t->queue > 1 || t->park < -1 || t->park > 1 || t->phase_vote < -1 || t->phase_vote > 64)
+        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.queue / park must be -1, 0 or 1; phase_vote -1 .. 64");
+    scene->tuning = *t;
     return 0;
 }
+
+int bt_scene_get_tuning(const bt_scene *scene, bt_tuning *out) {
+    if (!scene || !out) return set_error(BT_ERR_INVALID_ARG, "null argument");
+    *out = scene->tuning;
+    return 0;
+}
+
 const char *bt_version(void) { return "bendy-hip 0.1 (gfx950)"; }
 
 bt_scene *bt_scene_from_json(const char *json, size_t len) {
@@ -617,23 +670,29 @@ int bt_render_device(bt_scene *scene, uint64_t camera_ref, const bt_config *conf
 
 int bt_render(bt_scene *scene, uint64_t camera_ref, const bt_config *config, const bt_render_config *render,
               float *rgba_host, uint32_t width, uint32_t height, uint64_t seed) {
+    if (!scene) return set_error(BT_ERR_INVALID_ARG, "null scene");
     if (!rgba_host) return set_error(BT_ERR_INVALID_ARG, "null buffer");
     if (render && render->samples == 0) return BT_DONE;
     if (width == 0 || height == 0) return set_error(BT_ERR_INVALID_ARG, "zero-sized buffer");
+    int rc = ensure_device(scene);                        // binds the handle (and its cached frame) to the current device
+    if (rc) return rc;
     const size_t bytes = (size_t)width * height * 4 * sizeof(float);
-    float *d = nullptr;
-    BT_HIP(hipMalloc((void **)&d, bytes));
-    hipError_t e = hipMemcpy(d, rgba_host, bytes, hipMemcpyHostToDevice);
-    int rc = BT_ERR_DEVICE;
-    if (e == hipSuccess) {
-        rc = bt_render_device(scene, camera_ref, config, render, d, width, height, seed, nullptr);
-        if (rc >= 0) {
-            e = hipDeviceSynchronize();
-            if (e == hipSuccess) e = hipMemcpy(rgba_host, d, bytes, hipMemcpyDeviceToHost);
+    // the device copy of the caller's buffer lives on the handle: no hipMalloc / hipFree per displayed frame
+    if (scene->host_frame_bytes < bytes || scene->host_frame_bytes / 4 > bytes) {
+        if (scene->d_host_frame) {
+            BT_HIP(hipDeviceSynchronize());
+            (void)hipFree(scene->d_host_frame);
         }
+        scene->d_host_frame = nullptr;
+        scene->host_frame_bytes = 0;
+        BT_HIP(hipMalloc((void **)&scene->d_host_frame, bytes));
+        scene->host_frame_bytes = bytes;
     }
-    (void)hipFree(d);
-    if (e != hipSuccess) return set_error(BT_ERR_DEVICE, hipGetErrorString(e));
+    float *d = scene->d_host_frame;
+    BT_HIP(hipMemcpyAsync(d, rgba_host, bytes, hipMemcpyHostToDevice, nullptr));
+    rc = bt_render_device(scene, camera_ref, config, render, d, width, height, seed, nullptr);
+    if (rc < 0) return rc;
+    BT_HIP(hipMemcpy(rgba_host, d, bytes, hipMemcpyDeviceToHost));      // stream-ordered behind the kernel, blocks the host
     return rc;
 }
 

@@ -83,8 +83,23 @@ typedef struct {
     uint64_t lens_steps;       /* RK4 steps taken by the lens extension (0 when it is off) */
     uint32_t slices;           /* S of the last launch: workgroups own 256/S pixels and deal their samples to the lanes
                                 * through a queue (1 = a lane owns a pixel and all of its samples); DESIGN.md 5.3 */
-    uint32_t reserved;
+    uint32_t launches;         /* kernel launches the render was split into (deep renders under the scratch cap) */
+    uint64_t scratch_bytes;    /* HBM the handle holds for parked sample values after this render (0: none needed) */
+    uint64_t parked_bytes;     /* bytes of sample values the render parked in HBM (0 when they stayed in LDS / registers) */
 } bt_stats;
+
+/* Launch-shape knobs of a scene handle.  Every field's zero / negative value means "let the library decide" (what
+ * bt_tuning_default() fills in); the library itself never reads environment variables.  Tests and the A/B tools under
+ * tools/ set these to pin a shape; none of them can change a pixel (tests/test_gpu_parity.py renders every setting). */
+typedef struct {
+    uint32_t slices;           /* 0 = auto; 1, 2, 4, 8, 16, 32: a workgroup owns 256 / slices pixels */
+    uint32_t tiles_per_wg;     /* 0 = auto; 1, 2, 4: whole tiles per workgroup for shallow launches (slices == 1) */
+    int32_t queue;             /* -1 = auto; 0 = a lane owns a pixel (no parked samples); 1 = work queue */
+    int32_t phase_vote;        /* -1 = auto; 0 = off; n = longest wait in iterations (sphere-only builds) */
+    int32_t kernel_variant;    /* BT_KERNEL_DEFAULT / _LANES / _SORTED, per handle */
+    int32_t park;              /* -1 = auto; 0 = park sample values in HBM scratch; 1 = in LDS where the block fits */
+    uint64_t scratch_cap_bytes;/* 0 = default (2 GiB): deeper renders are split into several launches */
+} bt_tuning;
 
 /* EXTENSION -- NOT IN THE REFERENCE.  bendy-tracer v1 traces straight rays only (`Ray::at` is
  * origin + t * direction, tracer/ray.rs:115-117); "gravitational lensing" exists in its README as an
@@ -146,7 +161,9 @@ int bt_scene_export_prims(const bt_scene *scene, float *out, int cap);
  * SmallRng::from_entropy() (mod.rs:239-242).  Returns BT_DONE when samples == 0,
  * BT_IN_PROGRESS otherwise, < 0 on error.  Nothing is retained after return. */
 
-/* Host buffer (copies H2D, renders on the current device, copies D2H). */
+/* Host buffer: copies H2D into a device frame cached on the scene handle, renders on the current device, copies D2H
+ * (two PCIe transfers of w*h*16 bytes per call).  A caller that renders once per displayed frame (main.rs:245-254)
+ * should keep the frame on the device and use bt_render_device + bt_preview_device instead. */
 int bt_render(bt_scene *scene, uint64_t camera_ref, const bt_config *config, const bt_render_config *render,
               float *rgba_host, uint32_t width, uint32_t height, uint64_t seed);
 
@@ -172,21 +189,46 @@ int bt_render_shard_device(bt_scene *scene, uint64_t camera_ref, const bt_config
 int bt_unshard_device(const float *gathered_device, float *rgba_device, uint32_t width, uint32_t height,
                       uint32_t world, void *stream);
 
+/* The exchange step: one RCCL all-gather over xGMI of every rank's shard, one process per GPU.  RCCL is bound at run
+ * time (librccl.so.1; a copy the process already holds, e.g. PyTorch's, is shared).  Rank 0 obtains a unique id and
+ * hands it to the other ranks by any host-side channel (a file, a socket, MPI); bt_comm_init is collective. */
+#define BT_COMM_ID_BYTES 128
+typedef struct bt_comm bt_comm;
+/* ncclGetUniqueId: writes BT_COMM_ID_BYTES bytes, returns that count, < 0 on error. */
+int bt_comm_unique_id(void *id_out, size_t cap);
+/* ncclCommInitRank on the current device.  NULL on error (bt_last_error). */
+bt_comm *bt_comm_init(uint32_t rank, uint32_t world, const void *unique_id, size_t id_bytes);
+void bt_comm_free(bt_comm *comm);
+int bt_comm_rank(const bt_comm *comm);
+int bt_comm_world(const bt_comm *comm);
+/* ncclAllGather(shard -> gathered, bt_shard_floats(width, height, world) floats per rank) on `stream`. */
+int bt_allgather_shards_device(bt_comm *comm, const float *shard_device, float *gathered_device, uint32_t width,
+                               uint32_t height, void *stream);
+/* All-gather + bt_unshard_device: every rank ends up with the row-major frame of running sums in `rgba_device`
+ * (north_star: "RCCL all-gather over xGMI of the final framebuffer").  `gathered_device` is world * shard floats of
+ * staging the caller owns. */
+int bt_exchange_frame_device(bt_comm *comm, const float *shard_device, float *gathered_device, float *rgba_device,
+                             uint32_t width, uint32_t height, void *stream);
+
 /* --- Buffer::preview (tracer/buffer.rs:117-138): sum/samples -> colour space -> RGBA8 */
 int bt_preview_device(const float *rgba_device, uint8_t *rgba8_device, uint32_t width, uint32_t height,
                       uint32_t samples, int32_t color_space, void *stream);
 int bt_preview(const float *rgba_host, uint8_t *rgba8_host, uint32_t width, uint32_t height, uint32_t samples,
                int32_t color_space);
 
+void bt_tuning_default(bt_tuning *out);
+/* NULL restores the defaults.  Returns BT_ERR_INVALID_ARG for a value outside the sets above. */
+int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *tuning);
+int bt_scene_get_tuning(const bt_scene *scene, bt_tuning *out);
+
 /* Two bit-identical implementations of the render kernel exist:
  * BT_KERNEL_LANES  -- path state in registers; a workgroup owns a block of pixels and deals their samples to its lanes
  *                     through an LDS work queue, or a lane owns a pixel for very shallow launches (default, fastest
  *                     measured);
  * BT_KERNEL_SORTED -- path state in LDS, the workgroup re-sorts its 256 paths by pending event kind
- *                     every iteration (ballot / prefix-sum compaction).  Process-wide switch for A/B
- *                     measurements; BT_KERNEL_DEFAULT restores the built-in choice. */
+ *                     every iteration (ballot / prefix-sum compaction).  Selected per scene handle through
+ *                     bt_tuning.kernel_variant; BT_KERNEL_DEFAULT is the built-in choice (LANES). */
 enum { BT_KERNEL_DEFAULT = 0, BT_KERNEL_LANES = 1, BT_KERNEL_SORTED = 2 };
-int bt_set_kernel_variant(int variant);
 
 /* Work counters of the most recent bt_render* call on this handle (synchronises). */
 int bt_scene_last_stats(bt_scene *scene, bt_stats *out);

@@ -22,16 +22,19 @@ def oracle_render(o, name, w, h, spp, n=0, output=0, recursive=0, seed=0x5EED, t
     return img, seg
 
 
-def gpu_scene(b, name, w, h):
+def gpu_scene(b, name, w, h, tuning=None):
+    """`tuning`: bt_tuning fields (Scene.set_tuning) that pin the launch shape for this handle."""
     sc = b.Scene.load(scene_path(name))
     cam = sc.find_by_tag("camera")
     sc.set_camera_aspect(cam, w / h)
+    if tuning:
+        sc.set_tuning(**tuning)
     return sc, cam
 
 
-def gpu_render(b, name, w, h, spp, n=0, output=0, seed=0x5EED, device="cuda", **rc_kw):
+def gpu_render(b, name, w, h, spp, n=0, output=0, seed=0x5EED, device="cuda", tuning=None, **rc_kw):
     import torch
-    sc, cam = gpu_scene(b, name, w, h)
+    sc, cam = gpu_scene(b, name, w, h, tuning)
     buf = b.Buffer.new(w, h, device=device)
     tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4, output=b.Output(output)))
     st = tr.render(sc, cam, b.RenderConfig(samples=spp, subsample=b.Subsample(n), **rc_kw), buf, seed=seed)

@@ -227,3 +227,40 @@ def test_shard_geometry(bendy):
     assert bendy.shard_floats(100, 50, 3) == -(-(7 * 4) // 3) * 256 * 4      # padded to equal shards
     m = bendy.tile_owner_map(64, 48, 3)
     assert m.shape == (3, 4) and list(m.reshape(-1)) == [i % 3 for i in range(12)]
+
+
+def test_tuning_is_per_handle_and_validated(bendy, monkeypatch):
+    """bt_tuning (include/bendy_hip.h): launch-shape knobs live on the scene handle, not in the environment or in a
+    process global; out-of-set values are rejected; NULL restores the defaults."""
+    a = bendy.Scene.load(scene_path("scene"))
+    b = bendy.Scene.load(scene_path("scene"))
+    default = dict(slices=0, tiles_per_wg=0, queue=-1, phase_vote=-1, kernel_variant=0, park=-1, scratch_cap_bytes=0)
+    assert a.tuning() == default
+    a.set_tuning(slices=8, kernel_variant="sorted", scratch_cap_bytes=1 << 20)
+    assert a.tuning() == {**default, "slices": 8, "kernel_variant": 2, "scratch_cap_bytes": 1 << 20}
+    assert b.tuning() == default                     # another handle is untouched
+    a.set_tuning(phase_vote=0)                       # fields not named keep their value
+    assert a.tuning()["slices"] == 8 and a.tuning()["phase_vote"] == 0
+    for bad in (dict(slices=3), dict(tiles_per_wg=8), dict(kernel_variant=7), dict(queue=2), dict(park=-2)):
+        with pytest.raises(bendy.BendyError) as e:
+            a.set_tuning(**bad)
+        assert e.value.code == -1
+    a.set_tuning()
+    assert a.tuning() == default
+    # the library ignores the environment; only the helper for tools / tests translates it
+    monkeypatch.setenv("BT_SLICES", "16")
+    monkeypatch.setenv("BT_KERNEL", "sorted")
+    c = bendy.Scene.load(scene_path("scene"))
+    assert c.tuning() == default
+    assert c.tuning_from_env() == {"slices": 16, "kernel_variant": "sorted"} and c.tuning()["slices"] == 16
+    src = open(os.path.join(ROOT, "bendy_tracer_amd", "csrc", "bt_api.cpp")).read()
+    assert "getenv" not in src
+
+
+def test_default_sample_base_never_replays_indices(bendy):
+    """Tracer.render's default sample_base is the next UNUSED sample index: after 3 calls with Subsample::None a call with
+    Subpixel(2) must start at index ceil(3 / 4) = 1 of its own numbering, not at 0."""
+    buf = bendy.Buffer.new(4, 4, device="cpu")
+    buf.inc_samples(3)
+    nn = bendy.Subsample(2).subpixel_count()
+    assert (buf.samples + nn - 1) // nn == 1

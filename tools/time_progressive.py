@@ -1,5 +1,5 @@
 """Times the reference's interactive pattern (main.rs:245-254): one Tracer::render call per frame with samples = 1,
-Subpixel(2) (4 rays per pixel) on a 1080p frame, 50 calls (developer tool).  BT_SLICES forces the pixel-block split."""
+Subpixel(2) (4 rays per pixel) on a 1080p frame, 50 calls (developer tool).  bt_tuning pins the pixel-block split."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
@@ -9,12 +9,11 @@ for name in ('scene', 'cornell2', 'volume'):
     sc = b.Scene.load(f'scenes/{name}.json.gz'); cam = sc.find_by_tag('camera'); sc.set_camera_aspect(cam, w / h)
     tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
     for mode in ('auto', 't1', 't2', 't4', 'lanes'):   # tN = N whole tiles per workgroup; lanes = no work queue
-        os.environ.pop('BT_TILES_PER_WG', None)
-        os.environ.pop('BT_QUEUE', None)
+        sc.set_tuning()
         if mode == 'lanes':
-            os.environ['BT_QUEUE'] = '0'
+            sc.set_tuning(queue=0)
         elif mode != 'auto':
-            os.environ['BT_TILES_PER_WG'] = mode[1:]
+            sc.set_tuning(tiles_per_wg=int(mode[1:]))
         buf = b.Buffer.new(w, h)
         rc = b.RenderConfig.with_samples_subsample(1, b.Subsample(2))
         for i in range(5):

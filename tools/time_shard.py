@@ -1,5 +1,5 @@
 """Per-rank kernel time under bench.py's weak scaling, measured on one GPU (developer tool).
-usage: time_shard.py [scene] [BT_SLICES values, comma separated; "auto" = unset]"""
+usage: time_shard.py [scene] [bt_tuning.slices values, comma separated; "auto" = unset]"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
@@ -10,10 +10,7 @@ modes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['auto', '1']
 sc = b.Scene.load(f'scenes/{name}.json.gz'); cam = sc.find_by_tag('camera'); sc.set_camera_aspect(cam, w / h)
 tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
 for mode in modes:
-    if mode == 'auto':
-        os.environ.pop('BT_SLICES', None)
-    else:
-        os.environ['BT_SLICES'] = mode
+    sc.set_tuning(slices=0 if mode == 'auto' else int(mode))
     for world in (1, 2, 4, 8):
         spp = 64 * world
         for rank in sorted({0, world - 1}):

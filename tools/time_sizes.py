@@ -6,7 +6,7 @@ import bendy_tracer_amd as b
 for name in ('scene', 'cornell'):
     for spp in (4, 16, 64, 256, 1024):
         w, h = 1920, 1080
-        gs = b.Scene.load(f'scenes/{name}.json.gz'); cam = gs.find_by_tag('camera'); gs.set_camera_aspect(cam, w / h)
+        gs = b.Scene.load(f'scenes/{name}.json.gz'); cam = gs.find_by_tag('camera'); gs.set_camera_aspect(cam, w / h); gs.tuning_from_env()
         tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4)); buf = b.Buffer.new(w, h); ks=[]
         for it in range(4):
             tr.render(gs, cam, b.RenderConfig.with_samples(spp), buf, sample_base=it * spp); st=gs.last_stats(); ks.append(st.kernel_ms)

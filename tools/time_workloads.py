@@ -1,11 +1,15 @@
-"""Times the BASELINE workloads on the GPU (developer tool)."""
+"""Times the BASELINE workloads on the GPU (developer tool).  BT_SLICES / BT_QUEUE / BT_PHASE_VOTE / BT_PARK / ... in the
+environment are turned into bt_tuning fields here (Scene.tuning_from_env); the library does not read them."""
 import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
 import bendy_tracer_amd as b
+ONLY = os.environ.get('BT_ONLY', '').split(',') if os.environ.get('BT_ONLY') else None
 W = [('scene', 1920, 1080, 64), ('cornell2', 512, 512, 16), ('volume', 1920, 1080, 64), ('cornell', 1920, 1080, 64), ('cloud', 1920, 1080, 64)]
 for name, w, h, spp in W:
-    gs = b.Scene.load(f'scenes/{name}.json.gz'); cam = gs.find_by_tag('camera'); gs.set_camera_aspect(cam, w / h)
+    if ONLY and name not in ONLY:
+        continue
+    gs = b.Scene.load(f'scenes/{name}.json.gz'); cam = gs.find_by_tag('camera'); gs.set_camera_aspect(cam, w / h); gs.tuning_from_env()
     tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
     buf = b.Buffer.new(w, h)
     ks = []
