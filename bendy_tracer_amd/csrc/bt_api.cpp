@@ -75,6 +75,9 @@ struct bt_scene {
     DeviceArray<BtLight> d_lights;
     DeviceArray<BtLightFace> d_light_faces;
     DeviceArray<BtSpherePair> d_sphere_pairs;
+    DeviceArray<BtRectAAN> d_aan_rows;
+    DeviceArray<BtRectLA> d_la_rows;
+    DeviceArray<int32_t> d_other_rows;
     DeviceArray<float> d_density;
     DeviceArray<int32_t> d_lens_prims;     // lens extension: rows of d_prims near the sphere of influence
     bt_lens lens_prims_for{};              // the lens d_lens_prims was built for
@@ -170,6 +173,9 @@ int ensure_device(bt_scene *s) {
         BT_HIP(s->d_sphere_pairs.upload(pairs));
     }
     BT_HIP(s->d_density.upload(s->flat.density));
+    BT_HIP(s->d_aan_rows.upload(s->flat.aan_rows));
+    BT_HIP(s->d_la_rows.upload(s->flat.la_rows));
+    BT_HIP(s->d_other_rows.upload(s->flat.other_rows));
     if (!s->d_counters) BT_HIP(hipMalloc((void **)&s->d_counters, BT_N_COUNTERS * sizeof(unsigned long long)));
     if (!s->ev_start) BT_HIP(hipEventCreate(&s->ev_start));
     if (!s->ev_stop) BT_HIP(hipEventCreate(&s->ev_stop));
@@ -261,6 +267,12 @@ int fill_launch(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt
         if ((R.kind & BT_PRIM_SHAPE_MASK) != BT_PRIM_SPHERE) P.any_rects = 1;
         if (R.volume >= 0) P.any_volumes = 1;
     }
+    P.aan_rows = s->d_aan_rows.ptr;
+    P.la_rows = s->d_la_rows.ptr;
+    P.n_la = (int32_t)f.la_rows.size();
+    P.other_rows = s->d_other_rows.ptr;
+    P.n_aan[0] = f.n_aan[0]; P.n_aan[1] = f.n_aan[1]; P.n_aan[2] = f.n_aan[2];
+    P.n_other = (int32_t)f.other_rows.size();
     P.root_color = f.root_color;
     P.root_albedo = f.root_albedo;
     P.root_has_albedo = f.root_has_albedo;
@@ -293,6 +305,12 @@ int fill_launch(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt
     P.clip_min = cfg->clip_min;
     P.clip_max = cfg->clip_max;
     P.volume_step = rc->has_volume_step ? rc->volume_step : cfg->volume_step;                            // :227
+    // The build for rect scenes without volumes walks the sorted tables with a division whose range handling is hoisted
+    // out (bt_device.hpp div_refined): valid for 2^-30 <= clip_min, clip_max <= 2^60 and row ranks that fit 15 bits.  Any
+    // other rect scene runs the generic loop, which lives in the rects + volumes build.
+    if (P.any_rects && !P.any_volumes &&
+        !(P.clip_min >= 0x1p-30f && P.clip_max <= 0x1p60f && f.prims.size() < 0x7fffu))
+        P.any_volumes = 1;
     if (rc->samples > 0x7fffffffu / (n * n)) return set_error(BT_ERR_INVALID_ARG, "samples * n^2 overflows");
     P.samples = (int32_t)rc->samples;
     P.subsample_n = (int32_t)n;

@@ -355,8 +355,167 @@ BT_DEV HitRec intersect_spheres(const BtLaunch &P, V3 o, V3 d, float tmin, float
     return h;
 }
 
-template <bool RECTS = true, bool VOLS = true>
+// ---- rect scenes without volumes: rows grouped by kind, one refined reciprocal per group of parallel planes ----------
+// try_hit (mod.rs:389-402) keeps the smallest t and resolves exact ties by row order (a later plain rect / sphere
+// replaces an equal t, a later cuboid face does not).  The same winner falls out of ANY processing order when every hit
+// carries the rank `prio` of its row (bt_types.h BtRectAAN): smallest t, then largest prio -- the row that beats every
+// other row of its tie in try_hit's scan.  That frees the order, so the twelve axis-aligned rows of a Cornell box are
+// walked as three groups of parallel planes.
+struct SortedHit { float t; uint32_t prio; float psgn; };
+// The acceptance test of a rect row as ONE block of ISA: every condition narrows EXEC (v_cmpx), the running hit is then
+// overwritten with plain moves in the surviving lanes, EXEC is restored.  The compiler's form of the same test (a compare
+// into an SGPR pair per condition, s_and_b64 to combine them, v_cndmask per field) spends a dozen scalar instructions
+// per row, and the one scalar unit of a CU was the busiest part of the rect builds (profiles/r01g/pmcq_cornell_r01g.log:
+// 0.82 scalar instructions per CU-cycle).  ok_mask: lanes whose |q| passed the 1e-5 test (rect.rs:121-124);
+// a2 <= lim_a, b2 <= lim_b: Rect::contains_point (rect.rs:74-80); !(t < tmin): Clip (NaN passes, as in the C form, and
+// then fails the containment tests); t against the running hit: sorted_accept()'s rule.
+#ifndef BT_ACCEPT_ASM
+#define BT_ACCEPT_ASM 1
+#endif
+BT_DEV void sorted_accept_rect(SortedHit &h, unsigned long long ok_mask, float t, float tmin, float a2, float lim_a, float b2,
+                               float lim_b, uint32_t prio, float psgn) {
+#if BT_ACCEPT_ASM
+    unsigned long long saved, tmp;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_and_b64 exec, exec, %[okm]\n\t"
+                 "v_cmpx_ngt_f32 vcc, %[tmin], %[t]\n\t"
+                 "v_cmpx_ge_f32 vcc, %[lima], %[a2]\n\t"
+                 "v_cmpx_ge_f32 vcc, %[limb], %[b2]\n\t"
+                 "v_cmpx_le_f32 vcc, %[t], %[ht]\n\t"
+                 "v_cmp_eq_f32 vcc, %[t], %[ht]\n\t"
+                 "v_cmp_le_u32 %[tmp], %[prio], %[hp]\n\t"
+                 "s_and_b64 vcc, vcc, %[tmp]\n\t"
+                 "s_andn2_b64 exec, exec, vcc\n\t"
+                 "v_mov_b32 %[ht], %[t]\n\t"
+                 "v_mov_b32 %[hp], %[prio]\n\t"
+                 "v_mov_b32 %[hs], %[ps]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [ht] "+v"(h.t), [hp] "+v"(h.prio), [hs] "+v"(h.psgn), [sv] "=&s"(saved), [tmp] "=&s"(tmp)
+                 : [okm] "s"(ok_mask), [tmin] "s"(tmin), [t] "v"(t), [lima] "s"(lim_a), [a2] "v"(a2), [limb] "s"(lim_b),
+                   [b2] "v"(b2), [prio] "s"(prio), [ps] "v"(psgn)
+                 : "vcc", "scc");
+#else
+    const bool ok = ((ok_mask >> (threadIdx.x & 63)) & 1) & !(t < tmin) & (a2 <= lim_a) & (b2 <= lim_b);
+    const bool better = ok & ((t < h.t) | ((t == h.t) & (prio > h.prio)));
+    h.t = better ? t : h.t;
+    h.prio = better ? prio : h.prio;
+    h.psgn = better ? psgn : h.psgn;
+#endif
+}
+BT_DEV void sorted_accept(SortedHit &h, bool ok, float t, uint32_t prio, float psgn) {
+    const bool better = ok & ((t < h.t) | ((t == h.t) & (prio > h.prio)));
+    h.t = better ? t : h.t;
+    h.prio = better ? prio : h.prio;
+    h.psgn = better ? psgn : h.psgn;
+}
+// p / q by the sequence hipcc emits for an IEEE-754 binary32 division (v_rcp_f32, two Newton steps on the reciprocal,
+// quotient, two residual corrections; AMDGPU LowerFDIV32) WITHOUT its v_div_scale / v_div_fmas / v_div_fixup range
+// handling: identical bits whenever no intermediate leaves the normal range.  Here q = a component of a unit direction
+// with |q| > 1e-5 (smaller ones are a miss before t is looked at) and a hit needs clip_min <= t <= clip_max, so every
+// accepted t has |p| = |t q| within [clip_min 1e-5, 1.01 clip_max]; the host uses this path only for clip_min >= 2^-30,
+// clip_max <= 2^60 (bt_api.cpp).  A quotient outside that window is wrong at worst by being tiny, huge, inf or NaN --
+// it fails the clip / containment tests like the exact one.  `r` is the refined reciprocal: it depends on q alone.
+BT_DEV float refined_rcp(float q) {
+    const float r0 = __builtin_amdgcn_rcpf(q);
+    const float e0 = __builtin_fmaf(-q, r0, 1.0f);
+    return __builtin_fmaf(e0, r0, r0);
+}
+BT_DEV float div_refined(float p, float q, float r) {
+    const float m = p * r;
+    const float e = __builtin_fmaf(-q, m, p);
+    const float m2 = __builtin_fmaf(e, r, m);
+    const float e2 = __builtin_fmaf(-q, m2, p);
+    return __builtin_fmaf(e2, r, m2);
+}
+typedef const __attribute__((address_space(4))) BtRectAAN BtRectAANK;
+// one group of BT_PRIM_RECT_AAN rows with normal axis W: rect_aan_t<W>() with the division's reciprocal hoisted
+template <int W>
+BT_DEV void aan_group(BtRectAANK *rows, int n, V3 o, V3 d, float tmin, SortedHit &h) {
+    constexpr int A = W == 0 ? 1 : 0, B = W == 2 ? 1 : 2;
+    const float dq = BT_COMP(d, W), ow = BT_COMP(o, W);
+    const float oa = BT_COMP(o, A), da = BT_COMP(d, A), ob = BT_COMP(o, B), db = BT_COMP(d, B);
+    const float r = refined_rcp(dq);
+    const unsigned long long dq_ok = __builtin_amdgcn_ballot_w64(!(fabsf(dq) <= 1e-5f));
+    auto one = [&](BtRectAANK &R) {                 // wave-uniform row -> one s_load_dwordx8
+        const float dp = R.t_w - ow;
+        const float t = div_refined(dp, dq, r);     // == dp / dq (see above)
+        const float la = (oa + da * t) + R.it_a;
+        const float lb = (ob + db * t) + R.it_b;
+        sorted_accept_rect(h, dq_ok, t, tmin, la * la, R.lim_a, lb * lb, R.lim_b, R.prio, dp * R.sgn);
+    };
+    int i = 0;
+    for (; i + 1 < n; i += 2) {                     // two rows per trip: half the loop bookkeeping on the scalar unit
+        one(rows[i]);
+        one(rows[i + 1]);
+    }
+    if (i < n) one(rows[i]);
+}
+// the BT_PRIM_RECT_LA rows: rect_t()'s arithmetic with q = dot(d, n) and its reciprocal formed once per normal
+typedef const __attribute__((address_space(4))) BtRectLA BtRectLAK;
+BT_DEV void la_rows(BtRectLAK *rows, int n, V3 o, V3 d, float tmin, SortedHit &h) {
+    float q = 0.0f, r = 0.0f;
+    unsigned long long q_ok = 0;
+    for (int i = 0; i < n; ++i) {
+        BtRectLAK &R = rows[i];                     // wave-uniform index -> scalar loads
+        const V3 nrm = mk(R.n);
+        if (R.first_of_normal) {                    // wave-uniform
+            q = dot(d, nrm);
+            r = refined_rcp(q);
+            q_ok = __builtin_amdgcn_ballot_w64(!(fabsf(q) <= 1e-5f));
+        }
+        const float p = dot(mk(R.t) - o, nrm);
+        const float t = div_refined(p, q, r);       // == p / q
+        const V3 pos = o + d * t;
+        const f2 ax = {R.a_x[0], R.a_x[1]}, ay = {R.a_y[0], R.a_y[1]}, az = {R.a_z[0], R.a_z[1]}, aw = {R.a_w[0], R.a_w[1]};
+        const f2 l = ((ax * pos.x + ay * pos.y) + az * pos.z) + aw;       // (lu, lv) of rect_t()
+        const f2 l2 = l * l;
+        sorted_accept_rect(h, q_ok, t, tmin, l2.x, R.lim[0], l2.y, R.lim[1], R.prio, p);
+    }
+}
+BT_DEV HitRec intersect_sorted(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax) {
+    SortedHit h;
+    h.t = tmax;
+    h.prio = 0xffffu;                               // a strict row never replaces it at t == tmax, a plain one does
+    h.psgn = 0.0f;
+    BtRectAANK *aan = (BtRectAANK *)P.aan_rows;
+    if (P.n_aan[0]) aan_group<0>(aan, P.n_aan[0], o, d, tmin, h);
+    if (P.n_aan[1]) aan_group<1>(aan + P.n_aan[0], P.n_aan[1], o, d, tmin, h);
+    if (P.n_aan[2]) aan_group<2>(aan + P.n_aan[0] + P.n_aan[1], P.n_aan[2], o, d, tmin, h);
+    if (P.n_la) la_rows((BtRectLAK *)P.la_rows, P.n_la, o, d, tmin, h);
+    BtPrimK *prims = prim_table(P);
+    const __attribute__((address_space(4))) int32_t *rows = (const __attribute__((address_space(4))) int32_t *)P.other_rows;
+    for (int j = 0; j < P.n_other; ++j) {
+        const int row = rows[j];
+        BtPrimK &R = prims[row];
+        const bool strict = (R.kind & BT_PRIM_STRICT) != 0;
+        const uint32_t prio = strict ? 0xfffeu - (uint32_t)row : 0x10000u + (uint32_t)row;
+        if ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_SPHERE) {
+            // Sphere::hit (sphere.rs:121-148) against the running clip == the near root unless it lies before tmin, then
+            // the far one; accepted like every other hit (a root beyond the running clip loses the comparison)
+            const V3 oc = o - mk(R.c);
+            const float half_b = dot(oc, d), cc = len2(oc) - R.radius * R.radius;
+            const float disc = half_b * half_b - cc, sqrtd = sqrtf(disc);
+            const float t1 = -half_b - sqrtd, t2 = -half_b + sqrtd;
+            const float t = t1 < tmin ? t2 : t1;
+            sorted_accept(h, (disc >= 0.0f) & !(t < tmin), t, prio, 0.0f);
+        } else {
+            float t = 0.0f, q = 0.0f, p = 0.0f;
+            // the row's own clip tests run against [tmin, tmax]; the running clip is the comparison in sorted_accept
+            const bool hit = rect_t(o, d, R, tmin, __builtin_inff(), false, t, q, p);
+            sorted_accept(h, hit, t, prio, p);
+        }
+    }
+    HitRec out;
+    out.t = h.t;
+    out.inside = false;
+    out.p_neg = h.psgn < 0.0f;
+    out.prim = h.prio == 0xffffu ? -1 : (h.prio >= 0x10000u ? (int)(h.prio - 0x10000u) : (int)(0xfffeu - h.prio));
+    return out;
+}
+
+template <bool RECTS = true, bool VOLS = true, bool SORTED = false>
 BT_DEV HitRec intersect(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object, bool short_seg = false) {
+    if (SORTED) return intersect_sorted(P, o, d, tmin, tmax);
     if (!RECTS && !short_seg) return intersect_spheres<VOLS>(P, o, d, tmin, tmax, last_object);
     HitRec h;
     h.t = tmax;

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 h.p_neg = (held_info >> 30) & 1;
             } else {
                 segments += 1;
-                h = intersect<RECTS, VOLS>(P, ro, rd, tmin, tmax, last_object);
+                h = intersect<RECTS, VOLS, RECTS && !VOLS && !LENS>(P, ro, rd, tmin, tmax, last_object);
             }
             if (captured) {
                 ended = true;                         // swallowed by the horizon: the path returns black

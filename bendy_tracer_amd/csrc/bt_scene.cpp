@@ -441,6 +441,46 @@ FlatScene flatten_scene(const Scene &sc) {
         fs.root_albedo = shade_color;
         fs.root_color = add(shade_color, m.emitted);  // color_data.color += emitted (mod.rs:450)
     }
+    // sorted view of the table for bt_device.hpp intersect_sorted()
+    for (int axis = 0; axis < 3; ++axis)
+        for (size_t i = 0; i < fs.prims.size(); ++i) {
+            const BtPrim &p = fs.prims[i];
+            if ((p.kind & BT_PRIM_SHAPE_MASK) != BT_PRIM_RECT_AAN || p.aa_w != axis) continue;
+            BtRectAAN r{};
+            r.it_a = p.ax.y; r.it_b = p.ax.z; r.lim_a = p.ax_w; r.lim_b = p.ay.x; r.t_w = p.ax.x; r.sgn = p.ay.y;
+            r.prio = (p.kind & BT_PRIM_STRICT) ? 0xfffeu - (uint32_t)i : 0x10000u + (uint32_t)i;
+            fs.aan_rows.push_back(r);
+            fs.n_aan[axis] += 1;
+        }
+    {
+        // LA rows; a row whose normal equals (bit for bit) that of a row already emitted goes right behind it
+        std::vector<size_t> la;
+        for (size_t i = 0; i < fs.prims.size(); ++i)
+            if ((fs.prims[i].kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_RECT_LA) la.push_back(i);
+        std::vector<bool> done(la.size(), false);
+        auto same = [](const BtV3 &a, const BtV3 &b) { return std::memcmp(&a, &b, sizeof a) == 0; };
+        for (size_t a = 0; a < la.size(); ++a) {
+            if (done[a]) continue;
+            for (size_t b = a; b < la.size(); ++b) {
+                if (done[b] || !same(fs.prims[la[a]].c, fs.prims[la[b]].c)) continue;
+                const BtPrim &p = fs.prims[la[b]];
+                BtRectLA r{};
+                r.n = p.c;
+                r.first_of_normal = b == a ? 1u : 0u;
+                r.t = p.t;
+                r.prio = (p.kind & BT_PRIM_STRICT) ? 0xfffeu - (uint32_t)la[b] : 0x10000u + (uint32_t)la[b];
+                r.a_x[0] = p.ax.x; r.a_x[1] = p.ay.x; r.a_y[0] = p.ax.y; r.a_y[1] = p.ay.y; r.a_z[0] = p.ax.z; r.a_z[1] = p.ay.z;
+                r.a_w[0] = p.ax_w; r.a_w[1] = p.ay_w;
+                r.lim[0] = p.w_sqr; r.lim[1] = p.h_sqr;
+                fs.la_rows.push_back(r);
+                done[b] = true;
+            }
+        }
+    }
+    for (size_t i = 0; i < fs.prims.size(); ++i) {
+        const int shape = fs.prims[i].kind & BT_PRIM_SHAPE_MASK;
+        if (shape != BT_PRIM_RECT_AAN && shape != BT_PRIM_RECT_LA) fs.other_rows.push_back((int32_t)i);
+    }
     if (any_diffuse_used && fs.lights.empty())
         fail(BT_ERR_NO_LIGHT, "scene has a Diffuse material but no LIGHT object (Uniform::new(0, 0) would panic, material.rs:112)");
     return fs;

@@ -78,6 +78,11 @@ struct FlatScene {
     std::vector<BtLight> lights;
     std::vector<BtLightFace> light_faces;
     std::vector<float> density;
+    // rect scenes: the BT_PRIM_RECT_AAN rows grouped by normal axis + the rows of every other kind (bt_types.h BtRectAAN)
+    std::vector<BtRectAAN> aan_rows;
+    std::vector<BtRectLA> la_rows;
+    std::vector<int32_t> other_rows;
+    int32_t n_aan[3] = {0, 0, 0};
     BtV3 root_color{}, root_albedo{};
     int root_has_albedo = 0;
     size_t lds_bytes() const;

@@ -62,6 +62,35 @@ struct BtSpherePair {
 };
 static_assert(sizeof(BtSpherePair) == 48, "BtSpherePair must be 48 bytes");
 
+// Rect scenes without volumes: the BT_PRIM_RECT_AAN rows once more, 32 bytes each, grouped by the axis of the normal
+// (all x-normal rows, then y, then z; ascending row inside a group) -- bt_device.hpp intersect_sorted() walks a group
+// with one refined reciprocal of the ray direction's component for the whole group.  `prio` ranks the row for exact ties
+// in t, so that any processing order gives try_hit's result (mod.rs:389-402: rows in ascending order, a plain rect or
+// sphere accepts t <= clip.max, a cuboid face only t < clip.max): 0x10000 + row for the former, 0xfffe - row for the
+// latter (0xffff = no hit yet); the hit with the smallest t wins, among equal t the largest prio.
+struct BtRectAAN {
+    float it_a, it_b;       // it[a], it[b] of the inverse transform (a < b the in-plane axes): an aligned SGPR pair
+    float lim_a, lim_b;     // squared half extents along a, b
+    float t_w;              // t[w]
+    float sgn;              // c[w] = +-1
+    uint32_t prio;
+    uint32_t pad;
+};
+static_assert(sizeof(BtRectAAN) == 32, "BtRectAAN must be 32 bytes");
+// ... and the BT_PRIM_RECT_LA rows (every cuboid face under a rotation), rows with bitwise equal normals next to each
+// other: opposite faces of a cuboid share the normal (cuboid.rs:19-30), hence q = dot(d, n) and its reciprocal.  The two
+// rows of `M^-1 | t'` that the containment test needs sit side by side as pairs for packed arithmetic.
+struct BtRectLA {
+    BtV3 n;                 // world normal c = M * z
+    uint32_t first_of_normal; // 1: q and its reciprocal have to be formed for this row, 0: same normal as the row before
+    BtV3 t;                 // transform.translation
+    uint32_t prio;
+    float a_x[2], a_y[2], a_z[2], a_w[2];   // (ax, ay) component pairs; a_w = (ax_w, ay_w)
+    float lim[2];           // (w_sqr, h_sqr)
+    uint32_t pad[2];
+};
+static_assert(sizeof(BtRectLA) == 80, "BtRectLA must be 80 bytes");
+
 // Per-lane (divergent) lookups after the loop read this 32-byte digest from LDS.
 struct BtPrimLite {
     BtV3 c;             // sphere centre | rect world normal
@@ -121,7 +150,14 @@ struct BtLaunch {
     const float *density;
     int32_t n_prims, n_materials, n_volumes, n_lights, n_light_faces, n_density;
     int32_t any_rects;                // 0: every row of `prims` is a sphere (selects the build without rect code)
-    int32_t any_volumes;              // 0: no row carries a volume (selects the build without the march)
+    int32_t any_volumes;              // 0: no row carries a volume (selects the build without the march); the host also sets it
+                                      // when a rect scene cannot use the sorted tables below (the generic loop lives in that build)
+    // rect scenes without volumes (bt_device.hpp intersect_sorted): AAN rows grouped by normal axis, then every other row
+    const BtRectAAN *aan_rows;
+    const BtRectLA *la_rows;
+    const int32_t *other_rows;        // rows of `prims` that are neither BT_PRIM_RECT_AAN nor BT_PRIM_RECT_LA, ascending
+    int32_t n_aan[3];                 // x-, y-, z-normal rows of aan_rows (back to back)
+    int32_t n_la, n_other;
     // root material (mod.rs:429-452), precomputed ColorData of sample_root
     BtV3 root_color, root_albedo;
     int32_t root_has_albedo;
