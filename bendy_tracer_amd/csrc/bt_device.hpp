@@ -543,8 +543,11 @@ BT_DEV HitRec intersect_listed(const BtLaunch &P, V3 o, V3 d, float tmin, float 
 
 // Object::pdf of a light (object/mod.rs:154-166; sphere.rs:44-61, rect.rs:92-108,
 // cuboid.rs:56-81); 0 when the ray misses it (material.rs:313-316 unwrap_or_default).
-template <bool RECTS = true>
-BT_DEV float light_pdf(const BtLaunch &P, const BtLight &Lt, const SceneLds &S, V3 o, V3 d) {
+// LightRef / PrimTab: the light header and the primitive table through the LDS copy and the global pointer (light index
+// per lane), or both through the constant address space (scenes with ONE light, i.e. every bundled scene: the index is
+// wave-uniform, the rows arrive by scalar loads instead of per-lane global loads with their latency).
+template <bool RECTS, class LightRef, class PrimTab>
+BT_DEV float light_pdf_impl(const BtLaunch &P, LightRef &Lt, PrimTab prims, const SceneLds &S, V3 o, V3 d) {
     if (Lt.kind == BT_LIGHT_SPHERE) {
         float t;
         if (!sphere_t(o, d, mk(Lt.centre), Lt.radius, P.clip_min, P.clip_max, t)) return 0.0f;
@@ -552,7 +555,7 @@ BT_DEV float light_pdf(const BtLaunch &P, const BtLight &Lt, const SceneLds &S, 
     }
     if (RECTS && Lt.kind == BT_LIGHT_RECT) {
         float t, q, p;
-        if (!rect_t(o, d, P.prims[Lt.prim_first], P.clip_min, P.clip_max, false, t, q, p)) return 0.0f;
+        if (!rect_t(o, d, prims[Lt.prim_first], P.clip_min, P.clip_max, false, t, q, p)) return 0.0f;
         float shadow = S.faces[Lt.face_first].area * fabsf(q);
         return (t * t) / shadow;
     }
@@ -562,7 +565,7 @@ BT_DEV float light_pdf(const BtLaunch &P, const BtLight &Lt, const SceneLds &S, 
         for (int f = 0; f < Lt.prim_count; ++f) {
             float t, q, p;
             // rect.hit with the object-level clip, then `manifold.t < t` (cuboid.rs:63-75)
-            if (rect_t(o, d, P.prims[Lt.prim_first + f], P.clip_min, P.clip_max, false, t, q, p) && t < best_t) {
+            if (rect_t(o, d, prims[Lt.prim_first + f], P.clip_min, P.clip_max, false, t, q, p) && t < best_t) {
                 best_t = t;
                 best_q = q;
                 best = f;
@@ -573,6 +576,16 @@ BT_DEV float light_pdf(const BtLaunch &P, const BtLight &Lt, const SceneLds &S, 
         return (best_t * best_t) / shadow;
     }
     return 0.0f;
+}
+template <bool RECTS = true>
+BT_DEV float light_pdf(const BtLaunch &P, const BtLight &Lt, const SceneLds &S, V3 o, V3 d) {
+    return light_pdf_impl<RECTS>(P, Lt, P.prims, S, o, d);
+}
+typedef const __attribute__((address_space(4))) BtLight BtLightK;
+template <bool RECTS = true>
+BT_DEV float light_pdf_only_light(const BtLaunch &P, const SceneLds &S, V3 o, V3 d) {
+    BtLightK &Lt = *(BtLightK *)P.lights;
+    return light_pdf_impl<RECTS>(P, Lt, prim_table(P), S, o, d);
 }
 
 // Rect::random_point (rect.rs:82-86) on a light face

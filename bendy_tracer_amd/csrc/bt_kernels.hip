@@ -60,6 +60,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #define BT_WAVES_PER_SIMD_LENS 6       // lens builds: 80 VGPRs + ~100 B of scratch per lane still beat 4 waves without
 #endif                                 // scratch (665 -> 719 Msamples/s, profiles/r01g/ab_lens_waves.log)
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
+#ifndef BT_VOTE_RECTS
+#define BT_VOTE_RECTS 0            // phase voting in the rect builds too (A/B knob; measured in profiles/r02c)
+#endif
 #ifndef BT_LENS_BATCH
 #define BT_LENS_BATCH 8            // RK4 steps a lane marches per loop iteration before it yields
 #endif
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     uint32_t event = 0;
     bool pending = true;               // the lane has no ray yet: its next event is the camera ray
     // phase voting (BtLaunch::phase_vote): a lane whose scatter event lost the vote keeps its hit for the next iteration
-    constexpr bool VOTE = !RECTS && !LENS;    // pays where the events, not TRACE, are most of an iteration
+    constexpr bool VOTE = (!RECTS || BT_VOTE_RECTS) && !LENS;    // pays where the events, not TRACE, are most of an iteration
     bool held = false;
     float held_t = 0.0f;
     int held_info = 0, waited = 0;     // held_info = prim | inside << 29 | p_neg << 30
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             if (ev == EV_DIFFUSE) {
                 const BtLight &Lt = S.lights[(int)__umulhi(u.x, (uint32_t)P.n_lights)];
                 const float pd = dot(normal, nd) * 0.318309886183790671538f;   // diffuse_pdf (:301-303)
-                const float plight = light_pdf<RECTS>(P, Lt, S, pos, nd);
+                const float plight = P.n_lights == 1 ? light_pdf_only_light<RECTS>(P, S, pos, nd) : light_pdf<RECTS>(P, Lt, S, pos, nd);
                 const float p = lerpf(pd, plight, 0.5f);                  // :294-296
                 scatter = !(fabsf(p) <= 1e-5f);                           // Pdf::pdf (:279-286)
                 weight = pd / p;                                          // Material::pdf (:204) / shade.pdf
