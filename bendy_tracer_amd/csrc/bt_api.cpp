@@ -771,7 +771,15 @@ int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {
         BT_HIP(hipEventSynchronize(scene->ev_stop));
         unsigned long long c[BT_N_COUNTERS] = {0, 0};
         BT_HIP(hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
-#ifdef BT_PROFILE
+#ifdef BT_LANESTAT
+        // developer build (-DBT_LANESTAT): what the lanes of a wave do per iteration, see bt_kernels.hip
+        if (c[2]) {
+            const double it = (double)c[2] * 64.0;
+            fprintf(stderr, "[bt lanes] wave-iterations %llu; of 64 lanes per iteration: trace %.1f%% | camera %.1f%% diffuse %.1f%% metallic %.1f%% glass %.1f%% volume %.1f%% | waiting for phase %.1f%% | left the loop %.1f%%\n",
+                    c[2], 100.0 * c[3] / it, 100.0 * c[4] / it, 100.0 * c[5] / it, 100.0 * c[6] / it, 100.0 * c[7] / it,
+                    100.0 * c[8] / it, 100.0 * c[9] / it, 100.0 * c[10] / it);
+        }
+#elif defined(BT_PROFILE)
         // developer build (-DBT_PROFILE): wave cycles per section of the render loop, see bt_kernels.hip
         {
             unsigned long long tot = 0;

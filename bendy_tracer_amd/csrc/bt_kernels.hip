@@ -30,6 +30,14 @@
 
 // Developer build (-DBT_PROFILE): s_memtime stamps around the sections of the render loop, summed per wave into
 // counters[2..]; shares of wave cycles are printed by bt_scene_last_stats.  Not part of the product build.
+// Developer build (-DBT_LANESTAT, implies the 12 counters of BT_PROFILE): per wave-iteration popcounts of what the lanes
+// do, summed into counters[2..]: [2] wave iterations, [3] lanes that trace, [4..8] lanes per event kind (camera, Diffuse,
+// Metallic, Glass, volume), [9] lanes waiting for their phase, [10] lanes that have left the loop (queue empty).
+#ifdef BT_LANESTAT
+#define BT_LS(i, mask) do { ls_acc[i] += (unsigned long long)__popcll(mask); } while (0)   // every lane still in the loop counts; max over lanes at the end
+#else
+#define BT_LS(i, mask)
+#endif
 #ifdef BT_PROFILE
 #define BT_PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[BT_N_COUNTERS - 2] = {}
 #define BT_PROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
@@ -60,6 +68,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #define BT_WAVES_PER_SIMD_LENS 6       // lens builds: 80 VGPRs + ~100 B of scratch per lane still beat 4 waves without
 #endif                                 // scratch (665 -> 719 Msamples/s, profiles/r01g/ab_lens_waves.log)
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
+#ifndef BT_VOTE3
+#define BT_VOTE3 0                 // 1: builds with volumes vote between three kinds of event (measured slower, profiles/r02d/ab_vote3_rejected.log)
+#endif
 #ifndef BT_VOTE_RECTS
 #define BT_VOTE_RECTS 0            // phase voting in the rect builds too (A/B knob; measured in profiles/r02c)
 #endif
@@ -209,7 +220,13 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     };
 
     BT_PROF_DECL;
+#ifdef BT_LANESTAT
+    unsigned long long ls_acc[9] = {};
+    const unsigned long long ls_all = __ballot(true);
+#endif
     while (alive) {
+        BT_LS(0, 1ull);
+        BT_LS(8, ls_all & ~__ballot(true));
         BT_PROF(0);                                       // loop overhead / previous iteration's tail
         int ev = EV_GEN;
         // manifold of this iteration's hit (shading events only)
@@ -220,6 +237,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         V3 prim_c = mk(0, 0, 0);
         float prim_radius = 0.0f;
 
+        BT_LS(1, __ballot(!pending && !(VOTE && held)));
         if (!pending) {
             // ---- TRACE: try_hit (mod.rs:389-402) / try_hit_volume (mod.rs:404-427) ----
             const bool marching = VOLS && last_object >= 0;
@@ -316,17 +334,24 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         pending = false;
 
         if (VOTE && P.phase_vote) {
-            // ---- camera event or scatter events this iteration?  The kind more lanes want; nobody waits more than
-            // max_wait iterations.
-            // (a third phase for the volume steps alone was tried and lost, profiles/r01f/ab_phase_vote.log)
+            // ---- which events run this iteration?  The kind more lanes want; nobody waits more than max_wait iterations.
+            // Two kinds in builds without volumes (camera | scatter); three with them (camera | surface scatter | volume
+            // step): where paths march, the volume steps are most of a wave's events and the few surface lanes wait for
+            // company instead of dragging the Diffuse / light-pdf blocks through every iteration.
             const bool want_gen = ev == EV_GEN;
-            const unsigned long long m_gen = __ballot(want_gen), m_sc = __ballot(!want_gen);
-            const bool gen_phase = __popcll(m_gen) >= __popcll(m_sc);
-            // a lane of the losing side that has waited long enough is served in THIS iteration together with the
-            // winners (both kinds run, as without the vote) -- the majority does not lose an iteration to it
+            const bool want_vol = VOLS && BT_VOTE3 && ev == EV_VOLUME;
+            const bool want_sc = !want_gen && !want_vol;
+            const unsigned long long m_gen = __ballot(want_gen), m_sc = __ballot(want_sc), m_vol = (VOLS && BT_VOTE3) ? __ballot(want_vol) : 0ull;
+            const int n_gen = __popcll(m_gen), n_sc = __popcll(m_sc), n_vol = __popcll(m_vol);
+            // a lane of a losing side that has waited long enough is served in THIS iteration together with the winners
+            // (its whole kind runs, as without the vote) -- the majority does not lose an iteration to it
             const unsigned long long starving = __ballot(waited >= P.phase_vote);
-            const bool both = (starving & (gen_phase ? m_sc : m_gen)) != 0;
-            if (want_gen != gen_phase && !both) {
+            const bool run_gen = (n_gen >= n_sc && n_gen >= n_vol) || (starving & m_gen) != 0;
+            const bool run_sc = (n_sc > n_gen && n_sc >= n_vol) || (starving & m_sc) != 0;
+            const bool run_vol = (n_vol > n_gen && n_vol > n_sc) || (starving & m_vol) != 0;
+            const bool served = want_gen ? run_gen : (want_vol ? run_vol : run_sc);
+            BT_LS(7, __ballot(!served));
+            if (!served) {
                 waited += 1;
                 pending = want_gen;                   // no ray yet | the hit stays in held_t / held_info
                 held = !want_gen;
@@ -367,6 +392,8 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         }
         BT_PROF(1);                                       // TRACE + hit classification
 
+        BT_LS(2, __ballot(ev == EV_GEN)); BT_LS(3, __ballot(ev == EV_DIFFUSE)); BT_LS(4, __ballot(ev == EV_METALLIC));
+        BT_LS(5, __ballot(ev == EV_GLASS)); BT_LS(6, __ballot(ev == EV_VOLUME));
         // ---- the lane's one random event of this iteration (numerics contract N6) ----
         const uint32_t sample_index = sample0 + k;
         const U4 u = philox(pixel_index, sample_index, ev == EV_GEN ? 0u : event, 0u, P.seed_lo, P.seed_hi);
@@ -641,7 +668,16 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             unsigned long long ls = wave_sum(lens_steps);
             if (lane == 0 && ls) atomicAdd(&P.counters[1], ls);
         }
-#ifdef BT_PROFILE
+#ifdef BT_LANESTAT
+        for (int i = 0; i < 9; ++i) {
+            unsigned long long v = ls_acc[i];
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(v, off, 64);
+                v = o > v ? o : v;
+            }
+            if (lane == 0) atomicAdd(&P.counters[2 + i], v);
+        }
+#elif defined(BT_PROFILE)
         if (lane == 0)
             for (int i = 0; i < BT_N_COUNTERS - 2; ++i) atomicAdd(&P.counters[2 + i], prof_acc[i]);
 #endif

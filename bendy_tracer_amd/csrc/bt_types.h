@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 #define BT_TILE_DIM 16   // pixels per tile edge (== BT_TILE in include/bendy_hip.h)
-#ifdef BT_PROFILE
+#if defined(BT_PROFILE) || defined(BT_LANESTAT)
 #define BT_N_COUNTERS 12 // developer build: [2..] = wave cycles per section of the render loop
 #else
 #define BT_N_COUNTERS 2
