@@ -128,7 +128,8 @@ class Stats(C.Structure):
 
 class _CTuning(C.Structure):  # include/bendy_hip.h `bt_tuning`
     _fields_ = [("slices", C.c_uint32), ("tiles_per_wg", C.c_uint32), ("queue", C.c_int32), ("phase_vote", C.c_int32),
-                ("kernel_variant", C.c_int32), ("park", C.c_int32), ("scratch_cap_bytes", C.c_uint64)]
+                ("kernel_variant", C.c_int32), ("park", C.c_int32), ("scratch_cap_bytes", C.c_uint64),
+                ("workgroups_per_cu", C.c_uint32), ("ring_slots", C.c_uint32)]
 
 
 class _CLens(C.Structure):
@@ -331,10 +332,11 @@ class Scene:
 
     def tuning_from_env(self, environ=None):
         """Developer convenience for tools/ and tests/: BT_SLICES, BT_TILES_PER_WG, BT_QUEUE, BT_PHASE_VOTE, BT_KERNEL,
-        BT_PARK, BT_SCRATCH_CAP -> set_tuning().  The library itself never reads the environment."""
+        BT_PARK, BT_SCRATCH_CAP, BT_WGS_PER_CU, BT_RING_SLOTS -> set_tuning().  The library itself never reads the environment."""
         env = os.environ if environ is None else environ
         names = {"BT_SLICES": "slices", "BT_TILES_PER_WG": "tiles_per_wg", "BT_QUEUE": "queue",
-                 "BT_PHASE_VOTE": "phase_vote", "BT_PARK": "park", "BT_SCRATCH_CAP": "scratch_cap_bytes"}
+                 "BT_PHASE_VOTE": "phase_vote", "BT_PARK": "park", "BT_SCRATCH_CAP": "scratch_cap_bytes",
+                 "BT_WGS_PER_CU": "workgroups_per_cu", "BT_RING_SLOTS": "ring_slots"}
         knobs = {f: int(env[e]) for e, f in names.items() if env.get(e) not in (None, "", "-")}
         if env.get("BT_KERNEL") in self.KERNEL_VARIANTS:
             knobs["kernel_variant"] = env["BT_KERNEL"]

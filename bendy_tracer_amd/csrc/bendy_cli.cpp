@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bendy_hip.h"
@@ -157,6 +158,19 @@ int main(int argc, char **argv) {
     check(bt_scene_find_by_tag(scene, "camera", &camera), "find_by_tag(\"camera\")");          // main.rs:216
     check(bt_scene_set_camera_aspect(scene, camera, (float)args.width / (float)args.height), "aspect");  // :218-223
     if (args.has_lens) check(bt_scene_set_lens(scene, &args.lens), "bt_scene_set_lens");
+    {
+        // measurement harness: launch-shape knobs from the environment (the LIBRARY never reads it; this tool does, like
+        // tools/*.py through Scene.tuning_from_env)
+        bt_tuning t;
+        bt_tuning_default(&t);
+        bool any = false;
+        auto env = [&](const char *name, auto &field) {
+            if (const char *e = std::getenv(name)) { field = (std::remove_reference_t<decltype(field)>)std::strtoll(e, nullptr, 10); any = true; }
+        };
+        env("BT_SLICES", t.slices); env("BT_TILES_PER_WG", t.tiles_per_wg); env("BT_QUEUE", t.queue); env("BT_PHASE_VOTE", t.phase_vote);
+        env("BT_PARK", t.park); env("BT_SCRATCH_CAP", t.scratch_cap_bytes); env("BT_WGS_PER_CU", t.workgroups_per_cu); env("BT_RING_SLOTS", t.ring_slots);
+        if (any) check(bt_scene_set_tuning(scene, &t), "bt_scene_set_tuning");
+    }
 
     bt_config cfg;
     bt_config_default(&cfg);

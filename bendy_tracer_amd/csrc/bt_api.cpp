@@ -176,7 +176,7 @@ int ensure_device(bt_scene *s) {
     BT_HIP(s->d_aan_rows.upload(s->flat.aan_rows));
     BT_HIP(s->d_la_rows.upload(s->flat.la_rows));
     BT_HIP(s->d_other_rows.upload(s->flat.other_rows));
-    if (!s->d_counters) BT_HIP(hipMalloc((void **)&s->d_counters, BT_N_COUNTERS * sizeof(unsigned long long)));
+    if (!s->d_counters) BT_HIP(hipMalloc((void **)&s->d_counters, 16 * sizeof(unsigned long long)));
     if (!s->ev_start) BT_HIP(hipEventCreate(&s->ev_start));
     if (!s->ev_stop) BT_HIP(hipEventCreate(&s->ev_stop));
     s->device = dev;
@@ -381,10 +381,94 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     const uint64_t px_launch = (uint64_t)grid * BT_TILE_DIM * BT_TILE_DIM;
     uint32_t chunk = (uint32_t)P.samples;                         // samples per launch
     P.slices = 1;
+    P.tiles_per_wg = 1;
     P.scratch = nullptr;
+    P.stream = 0;
+    P.table_lds_bytes = (uint32_t)s->flat.lds_bytes();
+    size_t lds_bytes = s->flat.lds_bytes();
     // the launch should hold >= 4 x 20 waves per CU (tuned on the MI355X's 256 CUs as "4 * 5120 waves", round 1d)
     const uint64_t wave_slots = (uint64_t)s->n_cu * 20;
-    {
+    auto ensure_scratch = [&](uint64_t need) -> bool {
+        // grow when too small; give the memory back when this render needs less than a quarter of what is held
+        if (s->scratch_bytes >= need && s->scratch_bytes / 4 <= need) return true;
+        if (s->d_scratch) {
+            if (hipStreamSynchronize(stream) != hipSuccess) return false;   // an earlier launch on this stream may still read it
+            (void)hipFree(s->d_scratch);
+        }
+        s->d_scratch = nullptr;
+        s->scratch_bytes = 0;
+        if (need == 0) return true;
+        if (hipMalloc((void **)&s->d_scratch, need) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        s->scratch_bytes = need;
+        return true;
+    };
+    const uint64_t T_all = (uint64_t)P.samples * nn;
+    // 0 = a lane owns a pixel, 1 = block queue (the default whenever a pixel gets more than one ray), 2 = streaming queue
+    // (opt-in through bt_tuning.queue -- no multi-GB scratch, no drain at the end of a block, 65 x less HBM
+    // traffic with its ring in LDS, but 25 % slower on C3 as measured in round 2, profiles/r02e)
+    int qmode = T_all >= 2 ? 1 : 0;
+    if (tune.queue >= 0) qmode = tune.queue == 2 && P.lens_on ? 1 : tune.queue;
+    if (qmode == 2 && T_all * (uint64_t)BT_TILE_DIM * BT_TILE_DIM * grid >= (1ull << 40)) qmode = 1;   // item counters are 32 bit per workgroup
+    uint64_t parked_bytes = 0;
+    if (qmode == 2) {
+        // ---- streaming queue: persistent workgroups, a ring of parked units per workgroup ----
+        const uint32_t occ = 6u;           // workgroups per CU: every instantiation fits six (80 VGPRs, <= 112 SGPRs); a seventh that does not
+                                           // become resident would start only when a persistent workgroup ends
+        const uint32_t G_full = (uint32_t)s->n_cu * (tune.workgroups_per_cu ? tune.workgroups_per_cu : occ);
+        // pixel blocks: 64 pixels; smaller when the launch would otherwise have fewer than ~8 blocks per workgroup (the
+        // blocks are claimed dynamically, the last one a workgroup takes is its tail) -- but a block stays >= 1024 items
+        // (4 per lane), so that claiming one (a global atomic, microseconds) stays rare next to working one off
+        uint32_t S = 4;
+        while (S < 32 && (uint64_t)grid * S < 8ull * G_full && (uint64_t)(256u / (2 * S)) * T_all >= 1024) S *= 2;
+        if (tune.slices >= 4) S = tune.slices;
+        const uint32_t pxb = 256u / S;
+        const uint32_t T = (uint32_t)T_all;
+        // ring: four slots; in LDS when a unit of >= 64 items and >= ~6 items per lane in flight fit beside the tables
+        const uint32_t R = tune.ring_slots ? tune.ring_slots : 4;
+        const int64_t lds_budget = (int64_t)(160 * 1024 - 2048) / (tune.workgroups_per_cu ? tune.workgroups_per_cu : occ) - (int64_t)lds_bytes - 3 * 64 * 4 - 64;
+        const uint32_t tc_lds = lds_budget > 0 ? (uint32_t)(lds_budget / (int64_t)(R * pxb * 12)) : 0u;
+        bool ring_lds = tc_lds * pxb >= 256 && tc_lds >= 1;
+        if (tune.park >= 0) ring_lds = tune.park == 1 && tc_lds >= 1 && tc_lds * pxb >= 64;
+        uint32_t tc_max = ring_lds ? tc_lds : std::max(1u, 1024u / pxb);       // HBM ring: units of <= 1024 items
+        if (tc_max * pxb < 64) tc_max = 64 / pxb;
+        const uint32_t n_chunks = (T + tc_max - 1) / tc_max;
+        const uint32_t chunk_T = (T + n_chunks - 1) / n_chunks;                  // balanced chunks
+        // a unit must hold >= 64 items (a wave's 64 items span at most two units): the last chunk too
+        const uint32_t last_T = T - chunk_T * (n_chunks - 1);
+        if (last_T * pxb < 64 && n_chunks > 1) {
+            qmode = 1;                                                           // odd sample count that does not cut evenly: block queue
+        } else if (T * pxb < 64) {
+            qmode = T_all >= 2 ? 1 : 0;
+        } else {
+            P.stream = 1;
+            P.slices = (int32_t)S;
+            P.ring_slots = (int32_t)R;
+            P.ring_lds = ring_lds ? 1 : 0;
+            P.chunk_T = (int32_t)chunk_T;
+            P.n_chunks = (int32_t)n_chunks;
+            P.n_blocks = grid * S;
+            P.unit_cap = pxb * chunk_T;
+            P.stream_grid = std::min<uint32_t>(P.n_blocks, G_full);
+            P.block_counter = (uint32_t *)(s->d_counters + BT_BLOCK_COUNTER_SLOT);
+            P.tiles_x_magic = P.tiles_x == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / P.tiles_x);
+            lds_bytes += 3 * 64 * 4 + (ring_lds ? (size_t)R * P.unit_cap * 12 : 0);
+            const uint64_t need = ring_lds ? 0 : (uint64_t)P.stream_grid * R * P.unit_cap * 4 * sizeof(float);
+            if (!ensure_scratch(need)) return set_error(BT_ERR_DEVICE, "no device memory for the parked samples");
+            P.scratch = s->d_scratch;                                            // null with the ring in LDS
+            parked_bytes = ring_lds ? 0 : px_launch * T_all * 4 * sizeof(float);
+        }
+    }
+    if (qmode != 2 || !P.stream) {
+        // ---- block queue or one lane per pixel ----
+        // More than one ray per pixel -> a workgroup owns a block of 256 / S pixels and deals their samples to its lanes,
+        // every sample's value is parked in `scratch` (16 B per sample of the launch).  S is chosen so that a workgroup
+        // holds ~16 samples per lane (4 with the lens on, whose paths differ far more in length; down to 4 as well when
+        // the launch has too few pixels to fill the GPU).  A render whose scratch would exceed the cap is issued as several
+        // launches over consecutive sample ranges (k launches of m samples == one launch of k * m samples).  One ray per
+        // pixel, or no memory for the scratch -> the lanes kernel, which needs none.
         const uint64_t cap = tune.scratch_cap_bytes ? tune.scratch_cap_bytes : kDefaultScratchCap;
         auto pick = [&](uint64_t T) -> uint32_t {
             if (tune.slices) return tune.slices;
@@ -395,29 +479,12 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             while (S < 16 && waves * S < 4 * wave_slots && T / (2 * S) >= 4) S *= 2;
             return S;
         };
-        bool queue = (uint64_t)chunk * nn >= 2;
-        if (tune.queue >= 0) queue = tune.queue != 0;
+        bool queue = qmode != 0;
         if (queue) {
             const uint64_t per_sample = px_launch * nn * 4 * sizeof(float);
             if (per_sample * chunk > cap) chunk = (uint32_t)std::max<uint64_t>(1, cap / per_sample);
-            const uint64_t need = per_sample * chunk;
-            // grow when too small; give the memory back when this render needs less than a quarter of what is held
-            if (s->scratch_bytes < need || s->scratch_bytes / 4 > need) {
-                if (s->d_scratch) {
-                    BT_HIP(hipStreamSynchronize(stream));      // an earlier launch on this stream may still read it
-                    (void)hipFree(s->d_scratch);
-                }
-                s->d_scratch = nullptr;
-                s->scratch_bytes = 0;
-                if (hipMalloc((void **)&s->d_scratch, need) == hipSuccess) {
-                    s->scratch_bytes = need;
-                } else {
-                    (void)hipGetLastError();
-                    queue = false;
-                }
-            }
+            if (!ensure_scratch(per_sample * chunk)) queue = false;
         }
-        P.tiles_per_wg = 1;
         if (queue) {
             P.slices = (int32_t)pick((uint64_t)chunk * nn);
             P.scratch = s->d_scratch;
@@ -432,19 +499,20 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
                 tpw *= 2;
             if (tune.tiles_per_wg && P.slices == 1) tpw = tune.tiles_per_wg;
             P.tiles_per_wg = (int32_t)tpw;
+            parked_bytes = px_launch * T_all * 4 * sizeof(float);
         } else {
             chunk = (uint32_t)P.samples;
         }
     }
 
-    if (s->flat.lds_bytes() > 158 * 1024)
+    if (lds_bytes > 158 * 1024)
         return set_error(BT_ERR_INVALID_ARG, "scene tables (" + std::to_string(s->flat.lds_bytes()) +
                                                  " bytes) exceed the 160 KB of LDS of a gfx950 CU");
     // longest wait in iterations (0 = no voting); measured best: 3 on scene.json, 4 on the volume scenes
     // (profiles/r01f/ab_phase_vote.log, profiles/r01g/ab_vote_both.log)
     P.phase_vote = tune.phase_vote >= 0 ? tune.phase_vote : (P.any_volumes ? 4 : 3);
     uint32_t launches = 0;
-    BT_HIP(hipMemsetAsync(s->d_counters, 0, BT_N_COUNTERS * sizeof(unsigned long long), stream));
+    BT_HIP(hipMemsetAsync(s->d_counters, 0, 15 * sizeof(unsigned long long), stream));
     BT_HIP(hipEventRecord(s->ev_start, stream));
     // Two bit-identical kernels: the regrouping one (bt_kernels_sorted.hip, path state in LDS, lanes
     // re-sorted by event kind every iteration) and the lane-owns-pixel one (bt_kernels.hip).  The
@@ -457,6 +525,8 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     if (use_sorted) {                             // the regrouping kernel owns whole pixels
         P.slices = 1;
         P.scratch = nullptr;
+        P.stream = 0;
+        parked_bytes = 0;
         BT_HIP(bt_launch_render_sorted(&P, output, grid, s->flat.lds_bytes(), stream));
         launches = 1;
     } else {
@@ -464,7 +534,8 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         for (uint32_t done = 0; done < all; done += chunk) {
             P.samples = (int32_t)std::min(chunk, all - done);
             P.sample_base = base + done;
-            BT_HIP(bt_launch_render(&P, output, grid, s->flat.lds_bytes(), stream));
+            if (P.stream) BT_HIP(hipMemsetAsync(P.block_counter, 0, sizeof(unsigned long long), stream));
+            BT_HIP(bt_launch_render(&P, output, grid, lds_bytes, stream));
             launches += 1;
         }
         P.samples = (int32_t)all;
@@ -487,7 +558,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     s->last.slices = (uint32_t)P.slices;
     s->last.launches = launches;
     s->last.scratch_bytes = s->scratch_bytes;
-    s->last.parked_bytes = P.scratch ? s->last.samples * 4 * sizeof(float) : 0;
+    s->last.parked_bytes = parked_bytes;
     s->stats_pending = true;
     return BT_IN_PROGRESS;                                             // mod.rs:201
 }
@@ -539,8 +610,10 @@ int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
         return set_error(BT_ERR_INVALID_ARG, "bt_tuning.tiles_per_wg must be 0 (auto), 1, 2 or 4");
     if (t->kernel_variant != BT_KERNEL_DEFAULT && t->kernel_variant != BT_KERNEL_LANES && t->kernel_variant != BT_KERNEL_SORTED)
         return set_error(BT_ERR_INVALID_ARG, "unknown kernel variant");
-    if (t->queue < -1 || t->queue > 1 || t->park < -1 || t->park > 1 || t->phase_vote < -1 || t->phase_vote > 64)
-        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.queue / park must be -1, 0 or 1; phase_vote -1 .. 64");
+    if (t->workgroups_per_cu > 8 || !(t->ring_slots == 0 || t->ring_slots == 2 || t->ring_slots == 4))
+        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.workgroups_per_cu must be 0 .. 8, ring_slots 0, 2 or 4");
+    if (t->queue < -1 || t->queue > 2 || t->park < -1 || t->park > 1 || t->phase_vote < -1 || t->phase_vote > 64)
+        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.queue must be -1 .. 2, park -1, 0 or 1, phase_vote -1 .. 64");
     scene->tuning = *t;
     return 0;
 }
@@ -769,8 +842,11 @@ int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {
     if (!scene || !out) return set_error(BT_ERR_INVALID_ARG, "null argument");
     if (scene->stats_pending) {
         BT_HIP(hipEventSynchronize(scene->ev_stop));
-        unsigned long long c[BT_N_COUNTERS] = {0, 0};
+        unsigned long long c[16] = {0, 0};
         BT_HIP(hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
+#ifdef BT_STREAM_DEBUG                              // developer build of the whole library (FLAGS += -DBT_STREAM_DEBUG)
+        fprintf(stderr, "[bt stream] lane-iterations %llu, waiting for a ring slot %llu, claim-lock spins %llu; watchdog: slot wait %#llx %#llx, claim %#llx\n", c[3], c[4], c[5], c[6], c[7], c[8]);
+#endif
 #ifdef BT_LANESTAT
         // developer build (-DBT_LANESTAT): what the lanes of a wave do per iteration, see bt_kernels.hip
         if (c[2]) {

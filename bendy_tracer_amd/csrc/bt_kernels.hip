@@ -68,6 +68,8 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #define BT_WAVES_PER_SIMD_LENS 6       // lens builds: 80 VGPRs + ~100 B of scratch per lane still beat 4 waves without
 #endif                                 // scratch (665 -> 719 Msamples/s, profiles/r01g/ab_lens_waves.log)
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
+#define BT_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local")   // orders LDS accesses only (lgkmcnt)
+#define BT_RING_MAX 4               // most ring slots of the streaming queue (BtLaunch::ring_slots)
 #ifndef BT_VOTE3
 #define BT_VOTE3 0                 // 1: builds with volumes vote between three kinds of event (measured slower, profiles/r02d/ab_vote3_rejected.log)
 #endif
@@ -81,14 +83,36 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // lane-owns-pixel build keeps its registers and has no global stores inside the loop.
 // RECTS = false: sphere-only scenes (scene.json, volume.json, cloud.json) run a build without any rect / cuboid code.
 // VOLS = false: no sphere carries a volume (scene.json, the Cornell boxes): the march and Volume::shade drop out.
-template <int OUTPUT, bool LENS, bool SLICED, bool RECTS, bool VOLS>
+// QMODE: 0 = a lane owns a pixel; 1 = block queue (SLICED: a workgroup owns one pixel block, parks in HBM scratch); 2 = the
+// streaming queue (STREAM): a persistent workgroup walks its pixel blocks one after the other, see "streaming" below.
+template <int OUTPUT, bool LENS, int QMODE, bool RECTS, bool VOLS>
 __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : BT_WAVES_PER_SIMD)) void bt_render_kernel(BtLaunch P) {
+    constexpr bool SLICED = QMODE != 0;    // samples come from a work queue and are parked for the ordered sum
+    constexpr bool STREAM = QMODE == 2;
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint32_t s_waves_done;      // SLICED: waves of this workgroup that have parked all their samples
-    __shared__ uint32_t s_next_item;       // SLICED: the workgroup's work queue (next unclaimed (pixel, sample) pair)
+    __shared__ uint32_t s_waves_done;      // block queue: waves of this workgroup that have parked all their samples
+    __shared__ uint32_t s_next_item;       // the workgroup's work queue (next unclaimed (pixel, sample) pair)
+    __shared__ uint32_t s_summed;          // STREAM: units whose samples have been added to the frame (in order)
+    __shared__ uint32_t s_ready;           // STREAM: bit r = the unit in ring slot r is complete and waits for its sum
+    __shared__ uint32_t s_done[BT_RING_MAX]; // STREAM: finished items of the unit in ring slot r
+    __shared__ uint32_t s_blk[16];         // STREAM: the pixel block (launch order) behind this workgroup's n-th block, n mod 16
+    __shared__ uint32_t s_nclaimed;        // STREAM: blocks claimed so far
+    __shared__ uint32_t s_end_local;       // STREAM: this workgroup's first block number past the end of the launch
+    __shared__ uint32_t s_claim_lock;
     if (SLICED && threadIdx.x == 0) {
         s_waves_done = 0;
         s_next_item = 0;
+        s_summed = 0;
+        s_ready = 0;
+        for (int r = 0; r < BT_RING_MAX; ++r) s_done[r] = 0;
+        if (STREAM) {                       // the first two blocks of this workgroup's walk
+            const uint32_t b0 = atomicAdd(P.block_counter, 1u), b1 = b0 < P.n_blocks ? atomicAdd(P.block_counter, 1u) : b0;
+            s_blk[0] = b0;
+            s_blk[1] = b1;
+            s_nclaimed = b0 >= P.n_blocks ? 0u : (b1 >= P.n_blocks ? 1u : 2u);
+            s_end_local = b0 >= P.n_blocks ? 0u : (b1 >= P.n_blocks ? 1u : 0xffffffffu);
+            s_claim_lock = 0;
+        }
     }
 
     // ---- stage the per-lane lookup tables in LDS ----
@@ -123,6 +147,10 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         S.density = dens_lds ? dens : P.density;
         __syncthreads();
     }
+    // STREAM: behind the scene tables (BtLaunch::table_lds_bytes) the running sums of the block being summed and, when it
+    // fits, the ring of parked sample values
+    float *const s_accum = (float *)(smem + P.table_lds_bytes);
+    float *const ring_l = s_accum + 3 * 64;
 
     // ---- tile / pixel mapping ----
     // !SLICED: a workgroup is one 16x16 tile, wave w = its 8x8 quadrant w, a lane owns one pixel and walks that
@@ -162,11 +190,15 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
 
     // the lane's current pixel and sample: fixed pixel / k = 0, 1, ... when !SLICED, taken from the queue when SLICED
     uint32_t px, py, pixel_index, k = 0;
-    float4 *park = nullptr;                            // SLICED: where the current sample's value goes
+    float4 *park = nullptr;                            // block queue: where the current sample's value goes
+    // STREAM: the lane's item -- unit (sequence number in this workgroup's walk), place in the ring, state bits
+    uint32_t my_unit = 0, park_idx = 0, item_flags = 0;    // flags: 1 finished (to be counted), 2 reserved (waits for its ring slot), 4 last chunk
+    const uint32_t ring_items = STREAM ? (uint32_t)P.ring_slots * P.unit_cap : 0u;
     float *out_px = nullptr;
     bool alive;
     V3 acc = mk(0.0f, 0.0f, 0.0f);
     const uint32_t n_items = SLICED ? pxb * T : 0u;
+    const uint32_t LOG_PXB_ALL = (uint32_t)__builtin_ctz(pxb);
     if (SLICED) {
         px = py = pixel_index = 0;
         alive = true;                                  // until the workgroup's queue is empty (see the loop)
@@ -214,8 +246,189 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         if (!SLICED) {
             acc = acc + value;
             k += 1;
-        } else {
+        } else if (!STREAM) {
             *park = make_float4(value.x, value.y, value.z, 0.0f);
+        } else {
+            if (P.ring_lds) {
+                float *dst = ring_l + 3u * park_idx;
+                dst[0] = value.x; dst[1] = value.y; dst[2] = value.z;
+            } else {
+                ((float4 *)P.scratch)[(size_t)blockIdx.x * ring_items + park_idx] = make_float4(value.x, value.y, value.z, 0.0f);
+            }
+            item_flags |= 1u;                              // finished: counted at the next hand-out
+        }
+    };
+
+    // ---- streaming queue (QMODE 2) -------------------------------------------------------------------------------
+    // The launch is gridDim.x persistent workgroups; each claims pixel blocks (a block = pxb pixels of a tile, as in the
+    // block queue) one ahead of its need from a counter in HBM, so the blocks go to whoever is free -- a static deal
+    // (block w + n G to workgroup w) aliases with the tile rows and left the SIMDs 36 % empty on average
+    // (profiles/r02e/pmc_C3_q2_static.json).  A block's T samples are cut into n_chunks chunks of <= chunk_T; a
+    // UNIT = one block x one chunk = up to unit_cap items, and the workgroup's items are simply its units back to back:
+    // ONE counter in LDS hands them out, so a lane that has finished a sample flows on into the next unit -- and the next
+    // block -- without the drain at the end of every block that the block queue pays (10 % of all lane slots on
+    // volume.json, 28 % on the 512 x 512 Cornell box: profiles/r02d/lanestat_block_queue.log).  Sample values are parked
+    // in a ring of ring_slots unit-sized slots (LDS when it fits, else a small slice of HBM scratch per workgroup); the
+    // wave that finishes a unit's last item adds the unit to the running sums in sample order -- units strictly in
+    // sequence, so a pixel's chunks add up in order -- and only then may items of the unit ring_slots further on start.
+    const uint32_t R_MASK = STREAM ? (uint32_t)P.ring_slots - 1u : 0u;           // ring_slots is 2 or 4
+    const uint32_t LOG_PXB = STREAM ? (uint32_t)__builtin_ctz(pxb) : 0u, LOG_NS = STREAM ? (uint32_t)__builtin_ctz(NS) : 0u;
+    const uint32_t n_chunks = STREAM ? (uint32_t)P.n_chunks : 1u, chunk_T = STREAM ? (uint32_t)P.chunk_T : T;
+    const uint32_t last_T = T - chunk_T * (n_chunks - 1u);                      // samples of a block's last chunk
+#ifdef BT_STREAM_DEBUG
+    unsigned long long dbg_spins = 0, dbg_blocked = 0, dbg_iters = 0;
+#endif
+    // Makes sure this workgroup's blocks 0 .. upto have been claimed (wave-uniform; called when a wave's cursor enters
+    // block upto - 2, so the claim -- one global atomic, microseconds -- is long done when the first lane needs it).
+    auto ensure_claimed = [&](uint32_t upto) {
+        unsigned long long act;
+        asm volatile("s_mov_b64 %0, exec" : "=s"(act));
+        const int first = __ffsll((long long)act) - 1;
+        for (;;) {
+            BT_LDS_FENCE();
+            uint32_t nc = 0, end = 0, got = 1;
+            if ((int)lane == first) {
+                nc = __hip_atomic_load(&s_nclaimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                end = __hip_atomic_load(&s_end_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            nc = (uint32_t)__builtin_amdgcn_readlane((int)nc, first);
+            end = (uint32_t)__builtin_amdgcn_readlane((int)end, first);
+            if (nc > upto || end <= upto) break;                                  // claimed, or the launch has no blocks left
+            if ((int)lane == first) got = atomicCAS(&s_claim_lock, 0u, 1u);
+            got = (uint32_t)__builtin_amdgcn_readlane((int)got, first);
+            if (got != 0u) {                                                      // another wave is claiming
+#ifdef BT_STREAM_DEBUG
+                dbg_spins += 1;
+                if (dbg_spins > 200000ull) {
+                    if ((int)lane == first) atomicMax(&P.counters[8], (1ull << 60) | ((unsigned long long)upto << 40) | ((unsigned long long)nc << 20) | (end & 0xfffffu));
+                    break;
+                }
+#endif
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            BT_LDS_FENCE();
+            if ((int)lane == first) {
+                nc = __hip_atomic_load(&s_nclaimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                end = __hip_atomic_load(&s_end_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (nc <= upto && end > upto) {
+                    const uint32_t b = atomicAdd(P.block_counter, 1u);
+                    if (b < P.n_blocks) {
+                        __hip_atomic_store(&s_blk[nc & 15u], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local");
+                        atomicAdd(&s_nclaimed, 1u);
+                    } else {
+                        __hip_atomic_store(&s_end_local, nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // blocks nc, nc + 1, ... do not exist
+                    }
+                }
+            }
+            BT_LDS_FENCE();
+            if ((int)lane == first) atomicExch(&s_claim_lock, 0u);
+        }
+    };
+    // the wave's cursor: the unit that holds the items it was handed last (wave-uniform)
+    uint32_t u_seq = 0, u_start = 0, u_blk = 0, u_chunk = 0, u_items = pxb * (n_chunks == 1u ? T : chunk_T);
+    uint32_t sum_cache = 0;                                                     // the wave's last look at s_summed
+    // pixel q of block b (launch order) -- locate() with the block a per-lane value and every division a shift
+    auto locate_stream = [&](uint32_t b, uint32_t q) -> PixelRef {
+        const uint32_t slot = b >> LOG_NS, sub = b & (NS - 1u);
+        uint32_t bx, by;
+        if (LOG_PXB >= 6) {
+            const uint32_t quad = ((sub << LOG_PXB) + q) >> 6;
+            bx = ((quad & 1u) << 3) | (q & 7u);
+            by = ((quad >> 1) << 3) | ((q & 63u) >> 3);
+        } else {                                                                  // 8x4, 4x4, 4x2 pixels
+            const uint32_t lbw = LOG_PXB >= 5 ? 3u : 2u, lbh = LOG_PXB > lbw ? LOG_PXB - lbw : 0u, lnbx = 4u - lbw;
+            bx = ((sub & ((1u << lnbx) - 1u)) << lbw) + (q & ((1u << lbw) - 1u));
+            by = ((sub >> lnbx) << lbh) + (q >> lbw);
+        }
+        const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
+        uint32_t ty = __umulhi(tile, P.tiles_x_magic), tx = tile - ty * P.tiles_x;   // tile / tiles_x, exact after the fix-up
+        if (tx >= P.tiles_x) { ty += 1u; tx -= P.tiles_x; }
+        PixelRef r;
+        r.px = tx * BT_TILE_DIM + bx;
+        r.py = ty * BT_TILE_DIM + by;
+        r.in_frame = (ty < P.tiles_y) && (r.px < P.width) && (r.py < P.height);
+        r.out = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + by * BT_TILE_DIM + bx) * 4
+                          : P.out + ((size_t)r.py * P.width + r.px) * 4;
+        return r;
+    };
+    // Adds every complete unit, in sequence, to the running sums: `*r += pixel.r` (buffer.rs:159-164) in sample order.
+    // Called by a whole wave (every lane still in the loop) right after it finished a unit's last item.
+    auto sum_ready_units = [&]() {
+        // the lanes that execute THIS code: read EXEC in place (a `__ballot(true)` is an expression the optimizer may
+        // evaluate earlier in the iteration, where lanes that have since left for the loop head still count)
+        unsigned long long act;
+        asm volatile("s_mov_b64 %0, exec" : "=s"(act));
+        const int first = __ffsll((long long)act) - 1;
+        const uint32_t n_act = (uint32_t)__popcll(act);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        for (;;) {
+            // The protocol words s_summed / s_ready / s_done live in LDS and every access to them is ordered against the
+            // next by a sequentially consistent LDS fence: "my ready bit is set" must be visible before this wave looks at
+            // s_summed, and "s_summed has moved on" before it looks at the next unit's ready bit -- with relaxed atomics the
+            // compiler may swap two accesses to different words, and then a unit that completed out of order is left for
+            // a later completion to find (or, at the end of the workgroup's walk, for nobody).
+            BT_LDS_FENCE();
+            uint32_t cur = 0, was = 0;
+            if ((int)lane == first) cur = __hip_atomic_load(&s_summed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            cur = (uint32_t)__builtin_amdgcn_readlane((int)cur, first);
+            const uint32_t r = cur & R_MASK;
+            BT_LDS_FENCE();
+            if ((int)lane == first) was = atomicAnd(&s_ready, ~(1u << r));
+            was = (uint32_t)__builtin_amdgcn_readlane((int)was, first);
+            if (!(was & (1u << r))) break;                                        // not complete yet, or another wave has it
+            BT_LDS_FENCE();
+            if (!P.ring_lds) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // parked values in HBM: other waves' stores
+            const uint32_t blk = n_chunks == 1u ? cur : cur / n_chunks, chunk = cur - blk * n_chunks;
+            const uint32_t b = __hip_atomic_load(&s_blk[blk & 15u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t Tcu = chunk == n_chunks - 1u ? last_T : chunk_T;
+            const bool first_chunk = chunk == 0u, last_chunk = chunk == n_chunks - 1u;
+
+            for (uint32_t q = rank; q < pxb; q += n_act) {
+
+                const PixelRef pr = locate_stream(b, q);
+                V3 sum = mk(0.0f, 0.0f, 0.0f);
+                if (first_chunk) {
+                    if (pr.in_frame) sum = mk(pr.out[0], pr.out[1], pr.out[2]);
+                } else {
+                    sum = mk(s_accum[3u * q], s_accum[3u * q + 1u], s_accum[3u * q + 2u]);
+                }
+                if (pr.in_frame) {
+                    const uint32_t base_idx = r * P.unit_cap + q;
+                    if (P.ring_lds) {
+                        const float *src = ring_l + 3u * base_idx;
+                        for (uint32_t kk = 0; kk < Tcu; ++kk) {
+                            const float *v = src + 3u * (kk << LOG_PXB);
+                            sum = sum + mk(v[0], v[1], v[2]);
+                        }
+                    } else {
+                        const float4 *src = (const float4 *)P.scratch + (size_t)blockIdx.x * ring_items + base_idx;
+                        uint32_t kk = 0;
+                        for (; kk + 8 <= Tcu; kk += 8) {           // eight loads in flight, additions strictly in order
+                            float4 v[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j) << LOG_PXB];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
+                        }
+                        for (; kk < Tcu; ++kk) {
+                            const float4 v = src[(size_t)kk << LOG_PXB];
+                            sum = sum + mk(v.x, v.y, v.z);
+                        }
+                    }
+                }
+                if (last_chunk) {
+                    if (pr.in_frame) { pr.out[0] = sum.x; pr.out[1] = sum.y; pr.out[2] = sum.z; }
+                } else {
+                    s_accum[3u * q] = sum.x; s_accum[3u * q + 1u] = sum.y; s_accum[3u * q + 2u] = sum.z;
+                }
+            }
+            // the slot is free again: the unit ring_slots further on may start
+            BT_LDS_FENCE();
+            if ((int)lane == first) atomicExch(&s_done[r], 0u);
+            BT_LDS_FENCE();
+            if ((int)lane == first) atomicAdd(&s_summed, 1u);
         }
     };
 
@@ -225,6 +438,9 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     const unsigned long long ls_all = __ballot(true);
 #endif
     while (alive) {
+#ifdef BT_STREAM_DEBUG
+        dbg_iters += 1;
+#endif
         BT_LS(0, 1ull);
         BT_LS(8, ls_all & ~__ballot(true));
         BT_PROF(0);                                       // loop overhead / previous iteration's tail
@@ -364,6 +580,102 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         // ---- a lane whose path has ended (or that has none yet) moves on to its next sample ----
         if (!SLICED) {
             if (ev == EV_GEN && k >= T) break;                            // this pixel is done
+        } else if (STREAM) {
+            // the lanes that execute THIS code: EXEC read in place.  Every ballot below is masked with it -- a ballot is an
+            // expression the optimizer may evaluate earlier in the iteration, where lanes that have since gone back to the
+            // loop head (phase vote, waiting for a ring slot) still take part; counting one of those here would count its
+            // finished sample twice.
+            unsigned long long here;
+            asm volatile("s_mov_b64 %0, exec" : "=s"(here));
+            // (1) count the samples that have just ended: one LDS atomic per wave and ring slot; the wave that brings a
+            //     unit to its full count adds it (and every complete unit behind it) to the running sums
+            if (__ballot((item_flags & 1u) != 0u) & here) {
+                // the parked values before the count: LDS stores are ordered by the LDS fence; stores to the HBM ring
+                // have to be waited for (vmcnt)
+                if (P.ring_lds) BT_LDS_FENCE(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                for (uint32_t r = 0; r <= R_MASK; ++r) {
+                    const unsigned long long m = __ballot((item_flags & 1u) != 0u && (my_unit & R_MASK) == r) & here;
+                    if (!m) continue;                                     // wave-uniform
+                    const int leader = __ffsll((long long)m) - 1;
+                    const uint32_t cnt = (uint32_t)__popcll(m);
+                    uint32_t old_cnt = 0;
+                    if ((int)lane == leader) old_cnt = atomicAdd(&s_done[r], cnt);
+                    old_cnt = (uint32_t)__builtin_amdgcn_readlane((int)old_cnt, leader);
+                    const uint32_t unit_items = (uint32_t)__builtin_amdgcn_readlane((int)((item_flags & 4u) ? pxb * last_T : P.unit_cap), leader);
+                    if (old_cnt + cnt == unit_items) {
+                        BT_LDS_FENCE();
+                        if ((int)lane == leader) atomicOr(&s_ready, 1u << r);
+                        sum_ready_units();
+                    }
+                }
+                item_flags &= ~1u;
+            }
+            // (2) hand out new items
+            const bool want_item = ev == EV_GEN && !(item_flags & 2u);
+            const unsigned long long need = __ballot(want_item) & here;
+            if (need) {
+                const int leader = __ffsll((long long)need) - 1;
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&s_next_item, (uint32_t)__popcll(need));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                while (base >= u_start + u_items) {                       // move the wave's cursor to the unit that holds `base`
+                    u_start += u_items;
+                    u_seq += 1u;
+                    u_chunk += 1u;
+                    if (u_chunk == n_chunks) {
+                        u_chunk = 0u;
+                        u_blk += 1u;
+                        ensure_claimed(u_blk + 2u);                       // this block and the two after it
+                    }
+                    u_items = pxb * (u_chunk == n_chunks - 1u ? last_T : chunk_T);
+                }
+                if (want_item) {
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                    const uint32_t j = base + below;
+                    // a unit holds >= 64 items: the wave's 64 items lie in the cursor's unit or in the one after it
+                    const bool nxt = j >= u_start + u_items;
+                    const uint32_t n_chunk = u_chunk + 1u == n_chunks ? 0u : u_chunk + 1u;
+                    const uint32_t chunk_l = nxt ? n_chunk : u_chunk;
+                    const uint32_t blk_l = nxt && n_chunk == 0u ? u_blk + 1u : u_blk;
+                    const uint32_t within = j - (nxt ? u_start + u_items : u_start);
+                    my_unit = nxt ? u_seq + 1u : u_seq;
+                    k = chunk_l * chunk_T + (within >> LOG_PXB);
+                    park_idx = (my_unit & R_MASK) * P.unit_cap + within;
+                    if (blk_l >= *(volatile uint32_t *)&s_end_local) break;   // the launch has no blocks left: this lane is done
+                    const uint32_t gb = s_blk[blk_l & 15u];                 // claimed when the cursor entered block blk_l - 1
+                    const PixelRef r = locate_stream(gb, within & (pxb - 1u));
+                    px = r.px;
+                    py = r.py;
+                    item_flags = 2u | (chunk_l == n_chunks - 1u ? 4u : 0u) | (r.in_frame ? 8u : 0u);
+                }
+            }
+            // (3) a reserved item starts once its ring slot is free, i.e. the unit ring_slots before it has been summed
+            if (ev == EV_GEN) {
+                // s_summed only grows: the wave's copy is re-read only when it would hold a lane back
+                if (__ballot(my_unit > sum_cache + R_MASK) & here) sum_cache = *(volatile uint32_t *)&s_summed;
+                BT_LS(7, __ballot(my_unit > sum_cache + R_MASK) & here);   // (lanestat: counted with the phase waiters)
+                if (my_unit > sum_cache + R_MASK) {
+#ifdef BT_STREAM_DEBUG
+                    dbg_blocked += 1;
+                    if (dbg_blocked > 400000ull) {        // watchdog of the debug build: say where, and leave instead of hanging the GPU
+                        atomicMax(&P.counters[6], ((unsigned long long)my_unit << 40) | ((unsigned long long)(*(volatile uint32_t *)&s_summed) << 20) |
+                                                  ((unsigned long long)(*(volatile uint32_t *)&s_ready) << 16) | ((*(volatile uint32_t *)&s_done[(*(volatile uint32_t *)&s_summed) & R_MASK]) & 0xffffu));
+                        atomicMax(&P.counters[7], ((unsigned long long)(*(volatile uint32_t *)&s_nclaimed) << 40) | ((unsigned long long)(*(volatile uint32_t *)&s_end_local & 0xfffffu) << 20) | (*(volatile uint32_t *)&s_next_item & 0xfffffu));
+                        break;
+                    }
+#endif
+                    pending = true;
+                    continue;
+                }
+                item_flags &= ~2u;
+                if (!(item_flags & 8u)) {                                 // pixel outside the frame (edge tile): nothing to trace
+                    item_flags |= 1u;
+                    pending = true;
+                    continue;
+                }
+                pixel_index = py * P.width + px;
+            }
         } else {
             const unsigned long long need = __ballot(ev == EV_GEN);
             if (need) {                                                   // one LDS atomic for the whole wave
@@ -377,7 +689,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     const uint32_t i = base + below;
                     if (i >= n_items) break;                              // the block's samples are all taken
                     const uint32_t q = i & (pxb - 1);
-                    k = i / pxb;
+                    k = i >> LOG_PXB_ALL;                                 // pxb is a power of two
                     const PixelRef r = locate(q);
                     px = r.px;
                     py = r.py;
@@ -594,7 +906,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         out_px[1] = acc.y;
         out_px[2] = acc.z;
     }
-    if (SLICED) {
+    if (SLICED && !STREAM) {
         // The last wave of the workgroup to get here performs `*r += pixel.r` (buffer.rs:159-164) for every parked
         // sample of the block's pixels, in sample order -- the additions the unsliced kernel performs in registers,
         // in the same order.  The parked values were written by waves of this workgroup (same CU, same L1/L2), so
@@ -668,6 +980,12 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             unsigned long long ls = wave_sum(lens_steps);
             if (lane == 0 && ls) atomicAdd(&P.counters[1], ls);
         }
+#ifdef BT_STREAM_DEBUG
+        {   // debug build: lane-iterations | lane-iterations spent waiting for a ring slot | wave spins on the claim lock
+            const unsigned long long a = wave_sum(dbg_iters), b = wave_sum(dbg_blocked), c = wave_sum(dbg_spins);
+            if (lane == 0) { atomicAdd(&P.counters[3], a); atomicAdd(&P.counters[4], b); atomicAdd(&P.counters[5], c); }
+        }
+#endif
 #ifdef BT_LANESTAT
         for (int i = 0; i < 9; ++i) {
             unsigned long long v = ls_acc[i];
@@ -760,10 +1078,13 @@ __global__ __launch_bounds__(256) void bt_preview_kernel(const float4 *rgba, uin
 // ---- host-side launchers (called from bt_api.cpp) ---------------------------------------------
 extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream) {
-    // grid = tiles to render; with sample slicing a tile is S workgroups (see the mapping in the kernel)
-    const unsigned tpw = P->scratch ? (unsigned)P->tiles_per_wg : 1u;
-    dim3 g(tpw > 1 ? (grid + tpw - 1) / tpw : grid * (unsigned)P->slices), b(256);
-    const bool sliced = P->scratch != nullptr;      // the work-queue instantiation (any S, also whole tiles)
+    // grid = tiles to render; with sample slicing a tile is S workgroups (see the mapping in the kernel); the streaming
+    // queue launches P->stream_grid persistent workgroups instead
+    const unsigned tpw = P->scratch || P->stream ? (unsigned)P->tiles_per_wg : 1u;
+    dim3 g(P->stream ? P->stream_grid : (tpw > 1 ? (grid + tpw - 1) / tpw : grid * (unsigned)P->slices)), b(256);
+    // 0 = a lane owns a pixel, 1 = block queue (parks in scratch), 2 = streaming queue; the lens builds have no streaming
+    // instantiation (bt_api.cpp does not ask for one)
+    const int qmode = P->stream ? 2 : (P->scratch != nullptr ? 1 : 0);
     // scene classes: bit 0 = some sphere carries a volume (volume.json, cloud.json), bit 1 = rects / cuboids present
     // (the Cornell boxes); scene.json is class 0
     const int cls = (P->any_rects ? 2 : 0) | (P->any_volumes ? 1 : 0);
@@ -787,9 +1108,10 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
     if (cls == 3) { BT_LAUNCH_OUT(L, S, true, true) } else if (cls == 2) { BT_LAUNCH_OUT(L, S, true, false) }      \
     else if (cls == 1) { BT_LAUNCH_OUT(L, S, false, true) } else { BT_LAUNCH_OUT(L, S, false, false) }
     if (P->lens_on) {
-        if (sliced) { BT_LAUNCH_RECTS(true, true) } else { BT_LAUNCH_RECTS(true, false) }
+        if (qmode == 2) return hipErrorInvalidValue;
+        if (qmode == 1) { BT_LAUNCH_RECTS(true, 1) } else { BT_LAUNCH_RECTS(true, 0) }
     } else {
-        if (sliced) { BT_LAUNCH_RECTS(false, true) } else { BT_LAUNCH_RECTS(false, false) }
+        if (qmode == 2) { BT_LAUNCH_RECTS(false, 2) } else if (qmode == 1) { BT_LAUNCH_RECTS(false, 1) } else { BT_LAUNCH_RECTS(false, 0) }
     }
 #undef BT_LAUNCH_RECTS
 #undef BT_LAUNCH_OUT

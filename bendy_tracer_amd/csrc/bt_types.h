@@ -9,6 +9,7 @@
 #else
 #define BT_N_COUNTERS 2
 #endif
+#define BT_BLOCK_COUNTER_SLOT 15 // d_counters[15] is the streaming queue's block counter (the array holds 16 words)
 
 struct BtV3 { float x, y, z; };
 
@@ -190,6 +191,20 @@ struct BtLaunch {
     int32_t slices;                   // 1 = a lane owns all samples of its pixel (no scratch)
     int32_t tiles_per_wg;             // work-queue kernel, shallow launches: a workgroup owns 1, 2 or 4 whole tiles (slices == 1)
     float *scratch;
+    // Streaming queue (bt_kernels.hip "streaming"; bt_api.cpp decides): the launch is stream_grid persistent workgroups,
+    // workgroup w walks the pixel blocks w, w + stream_grid, ...; a block's samples are cut into n_chunks chunks of
+    // <= chunk_T; the values of a unit (block x chunk, <= unit_cap items) are parked in one of ring_slots slots -- in LDS
+    // behind the scene tables (ring_lds) or at scratch[workgroup * ring_slots * unit_cap ...] (float4 each).
+    int32_t stream;                   // 1: streaming queue (slices = blocks per tile, 4 .. 32; tiles_per_wg = 1)
+    int32_t ring_slots;               // 2 or 4
+    int32_t ring_lds;
+    int32_t chunk_T, n_chunks;
+    uint32_t n_blocks;                // pixel blocks of this launch = tiles of the launch * slices
+    uint32_t unit_cap;                // (256 / slices) * chunk_T
+    uint32_t stream_grid;
+    uint32_t *block_counter;          // next unclaimed pixel block of the launch (zeroed before every launch)
+    uint32_t tiles_x_magic;           // floor(2^32 / tiles_x) + 1: tile / tiles_x = umulhi(tile, magic), fixed up by one step
+    uint32_t table_lds_bytes;         // bytes of the scene tables at the start of dynamic LDS
     // Phase voting (bt_kernels.hip, sphere-only builds): every iteration the wave runs EITHER the camera event OR the
     // scatter / volume events, whichever more of its lanes want; the others keep what they have (no ray yet, or their
     // hit) for the next iteration, at most phase_vote iterations in a row (0 = off).  Scheduling only: every lane

@@ -92,13 +92,17 @@ typedef struct {
  * bt_tuning_default() fills in); the library itself never reads environment variables.  Tests and the A/B tools under
  * tools/ set these to pin a shape; none of them can change a pixel (tests/test_gpu_parity.py renders every setting). */
 typedef struct {
-    uint32_t slices;           /* 0 = auto; 1, 2, 4, 8, 16, 32: a workgroup owns 256 / slices pixels */
+    uint32_t slices;           /* 0 = auto; 1, 2, 4, 8, 16, 32: pixel blocks of 256 / slices pixels (streaming queue: >= 4) */
     uint32_t tiles_per_wg;     /* 0 = auto; 1, 2, 4: whole tiles per workgroup for shallow launches (slices == 1) */
-    int32_t queue;             /* -1 = auto; 0 = a lane owns a pixel (no parked samples); 1 = work queue */
+    int32_t queue;             /* -1 = auto; 0 = a lane owns a pixel (no parked samples); 1 = block queue (a workgroup per pixel
+                                * block; what auto picks for more than one ray per pixel); 2 = streaming queue (persistent
+                                * workgroups claim pixel blocks and park sample values in a small ring, in LDS when it fits) */
     int32_t phase_vote;        /* -1 = auto; 0 = off; n = longest wait in iterations (sphere-only builds) */
     int32_t kernel_variant;    /* BT_KERNEL_DEFAULT / _LANES / _SORTED, per handle */
-    int32_t park;              /* -1 = auto; 0 = park sample values in HBM scratch; 1 = in LDS where the block fits */
-    uint64_t scratch_cap_bytes;/* 0 = default (2 GiB): deeper renders are split into several launches */
+    int32_t park;              /* streaming queue: -1 = auto; 0 = the ring of parked sample values in HBM scratch; 1 = in LDS */
+    uint64_t scratch_cap_bytes;/* block queue: 0 = default (2 GiB); deeper renders are split into several launches */
+    uint32_t workgroups_per_cu;/* streaming queue: 0 = auto; persistent workgroups launched per CU (1 .. 8) */
+    uint32_t ring_slots;       /* streaming queue: 0 = auto; 2 or 4 parking slots per workgroup */
 } bt_tuning;
 
 /* EXTENSION -- NOT IN THE REFERENCE.  bendy-tracer v1 traces straight rays only (`Ray::at` is

@@ -535,3 +535,56 @@ def test_many_objects(bendy, oracle):
     from scene_gen import random_scene
     gs = _compare_json_scene(bendy, oracle, random_scene(7, n_objects=60, n_lights=(4, 4)), 64, 40, 2)
     assert gs.export_prims().shape[0] > 100
+
+
+# ---- the streaming queue (bt_tuning.queue = 2): persistent workgroups claim pixel blocks, ring of parked units ------
+@pytest.mark.parametrize("park", [0, 1])
+@pytest.mark.parametrize("name,w,h,spp,n,output,slices", [
+    ("scene", 96, 54, 24, 0, 0, 0), ("cornell", 70, 41, 24, 0, 0, 32), ("cloud", 200, 120, 37, 0, 0, 0),
+    ("volume", 96, 64, 16, 0, 0, 8), ("cornell2", 150, 75, 3, 2, 0, 4), ("scene", 320, 180, 64, 0, 0, 16),
+    ("scene", 64, 48, 8, 0, 1, 0), ("cornell", 64, 48, 8, 0, 2, 0), ("volume", 64, 48, 8, 0, 3, 4)])
+def test_streaming_queue_matches_oracle(bendy, oracle, name, w, h, spp, n, output, slices, park):
+    """Same bits as the oracle (and therefore as the block queue) for ragged frames, every block size, chunked units,
+    odd sample counts, Subpixel(2), every Output -- with the ring of parked values in LDS and in HBM."""
+    tuning = {"queue": 2, "park": park, "slices": slices}
+    buf, stats, _ = gpu_render(bendy, name, w, h, spp, n=n, output=output, tuning=tuning)
+    it, seg = oracle_render(oracle, name, w, h, spp, n=n, output=output)
+    assert stats.segments == seg and np.array_equal(buf.numpy(), it)
+    # the ring is a few MB at most, never the 16 B per sample of the block queue
+    assert stats.scratch_bytes <= 256 * 8 * 4 * 1024 * 16
+
+
+def test_streaming_queue_progressive_sharded_and_prefilled(bendy, oracle):
+    """Progressive calls into a pre-filled buffer (main.rs:245-254) and the sharded layout (3 ranks, ragged) through the
+    streaming queue."""
+    import torch
+    w, h, world = 70, 41, 3
+    tuning = {"queue": 2}
+    sc, cam = gpu_scene(bendy, "cornell", w, h, tuning=tuning)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    buf = bendy.Buffer.new(w, h)
+    for _ in range(3):
+        tr.render(sc, cam, bendy.RenderConfig.with_samples(8), buf)
+    it, _ = oracle_render(oracle, "cornell", w, h, 24)
+    assert buf.samples == 24 and np.array_equal(buf.numpy(), it)
+    shards = []
+    for r in range(world):
+        s = bendy.new_shard(w, h, world)
+        tr.render_shard(sc, cam, bendy.RenderConfig.with_samples(24), s, w, h, r, world)
+        shards.append(s)
+    out = bendy.Buffer.new(w, h)
+    bendy.unshard(torch.cat(shards), out, world)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.numpy(), it)
+
+
+def test_streaming_queue_full_size_equals_block_queue(bendy):
+    """C3 and C4 at full size: the streaming queue (ring in LDS / in HBM) gives the block queue's frame bit for bit, with
+    no scratch (LDS) or a ring of ~100 MB (HBM) instead of 2 GB."""
+    for name in ("scene", "volume"):
+        a, sa, _ = gpu_render(bendy, name, 1920, 1080, 64, tuning={"queue": 1})
+        assert sa.parked_bytes >= 1920 * 1080 * 64 * 16                   # 16 B per sample (edge tiles padded)
+        for park in (1, 0):
+            b_, sb, _ = gpu_render(bendy, name, 1920, 1080, 64, tuning={"queue": 2, "park": park})
+            assert sb.segments == sa.segments and np.array_equal(a.numpy(), b_.numpy())
+            assert sb.scratch_bytes == 0 if sb.parked_bytes == 0 else sb.scratch_bytes < 256 * 1024 * 1024

@@ -234,14 +234,15 @@ def test_tuning_is_per_handle_and_validated(bendy, monkeypatch):
     process global; out-of-set values are rejected; NULL restores the defaults."""
     a = bendy.Scene.load(scene_path("scene"))
     b = bendy.Scene.load(scene_path("scene"))
-    default = dict(slices=0, tiles_per_wg=0, queue=-1, phase_vote=-1, kernel_variant=0, park=-1, scratch_cap_bytes=0)
+    default = dict(slices=0, tiles_per_wg=0, queue=-1, phase_vote=-1, kernel_variant=0, park=-1, scratch_cap_bytes=0,
+                   workgroups_per_cu=0, ring_slots=0)
     assert a.tuning() == default
     a.set_tuning(slices=8, kernel_variant="sorted", scratch_cap_bytes=1 << 20)
     assert a.tuning() == {**default, "slices": 8, "kernel_variant": 2, "scratch_cap_bytes": 1 << 20}
     assert b.tuning() == default                     # another handle is untouched
     a.set_tuning(phase_vote=0)                       # fields not named keep their value
     assert a.tuning()["slices"] == 8 and a.tuning()["phase_vote"] == 0
-    for bad in (dict(slices=3), dict(tiles_per_wg=8), dict(kernel_variant=7), dict(queue=2), dict(park=-2)):
+    for bad in (dict(slices=3), dict(tiles_per_wg=8), dict(kernel_variant=7), dict(queue=3), dict(park=-2), dict(ring_slots=3), dict(workgroups_per_cu=9)):
         with pytest.raises(bendy.BendyError) as e:
             a.set_tuning(**bad)
         assert e.value.code == -1
