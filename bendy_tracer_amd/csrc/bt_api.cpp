@@ -455,10 +455,10 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             P.block_counter = (uint32_t *)(s->d_counters + BT_BLOCK_COUNTER_SLOT);
             P.tiles_x_magic = P.tiles_x == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / P.tiles_x);
             lds_bytes += 3 * 64 * 4 + (ring_lds ? (size_t)R * P.unit_cap * 12 : 0);
-            const uint64_t need = ring_lds ? 0 : (uint64_t)P.stream_grid * R * P.unit_cap * 4 * sizeof(float);
+            const uint64_t need = ring_lds ? 0 : (uint64_t)P.stream_grid * R * P.unit_cap * 3 * sizeof(float);
             if (!ensure_scratch(need)) return set_error(BT_ERR_DEVICE, "no device memory for the parked samples");
             P.scratch = s->d_scratch;                                            // null with the ring in LDS
-            parked_bytes = ring_lds ? 0 : px_launch * T_all * 4 * sizeof(float);
+            parked_bytes = ring_lds ? 0 : px_launch * T_all * 3 * sizeof(float);
         }
     }
     if (qmode != 2 || !P.stream) {
@@ -481,7 +481,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         };
         bool queue = qmode != 0;
         if (queue) {
-            const uint64_t per_sample = px_launch * nn * 4 * sizeof(float);
+            const uint64_t per_sample = px_launch * nn * 3 * sizeof(float);      // 12 B per parked sample value
             if (per_sample * chunk > cap) chunk = (uint32_t)std::max<uint64_t>(1, cap / per_sample);
             if (!ensure_scratch(per_sample * chunk)) queue = false;
         }
@@ -499,7 +499,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
                 tpw *= 2;
             if (tune.tiles_per_wg && P.slices == 1) tpw = tune.tiles_per_wg;
             P.tiles_per_wg = (int32_t)tpw;
-            parked_bytes = px_launch * T_all * 4 * sizeof(float);
+            parked_bytes = px_launch * T_all * 3 * sizeof(float);
         } else {
             chunk = (uint32_t)P.samples;
         }

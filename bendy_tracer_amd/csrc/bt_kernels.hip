@@ -48,6 +48,9 @@
 
 namespace {
 
+// A parked sample value: 12 bytes (round 1 parked a float4 with an unused w -- a quarter of the block queue's HBM traffic).
+struct Parked { float x, y, z; };
+
 enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 };
 
 } // namespace
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
 
     // the lane's current pixel and sample: fixed pixel / k = 0, 1, ... when !SLICED, taken from the queue when SLICED
     uint32_t px, py, pixel_index, k = 0;
-    float4 *park = nullptr;                            // block queue: where the current sample's value goes
+    Parked *park = nullptr;                            // block queue: where the current sample's value goes
     // STREAM: the lane's item -- unit (sequence number in this workgroup's walk), place in the ring, state bits
     uint32_t my_unit = 0, park_idx = 0, item_flags = 0;    // flags: 1 finished (to be counted), 2 reserved (waits for its ring slot), 4 last chunk
     const uint32_t ring_items = STREAM ? (uint32_t)P.ring_slots * P.unit_cap : 0u;
@@ -247,13 +250,13 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             acc = acc + value;
             k += 1;
         } else if (!STREAM) {
-            *park = make_float4(value.x, value.y, value.z, 0.0f);
+            *park = Parked{value.x, value.y, value.z};
         } else {
             if (P.ring_lds) {
                 float *dst = ring_l + 3u * park_idx;
                 dst[0] = value.x; dst[1] = value.y; dst[2] = value.z;
             } else {
-                ((float4 *)P.scratch)[(size_t)blockIdx.x * ring_items + park_idx] = make_float4(value.x, value.y, value.z, 0.0f);
+                ((Parked *)P.scratch)[(size_t)blockIdx.x * ring_items + park_idx] = Parked{value.x, value.y, value.z};
             }
             item_flags |= 1u;                              // finished: counted at the next hand-out
         }
@@ -403,17 +406,17 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                             sum = sum + mk(v[0], v[1], v[2]);
                         }
                     } else {
-                        const float4 *src = (const float4 *)P.scratch + (size_t)blockIdx.x * ring_items + base_idx;
+                        const Parked *src = (const Parked *)P.scratch + (size_t)blockIdx.x * ring_items + base_idx;
                         uint32_t kk = 0;
                         for (; kk + 8 <= Tcu; kk += 8) {           // eight loads in flight, additions strictly in order
-                            float4 v[8];
+                            Parked v[8];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j) << LOG_PXB];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
                         }
                         for (; kk < Tcu; ++kk) {
-                            const float4 v = src[(size_t)kk << LOG_PXB];
+                            const Parked v = src[(size_t)kk << LOG_PXB];
                             sum = sum + mk(v.x, v.y, v.z);
                         }
                     }
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                         continue;
                     }
                     pixel_index = py * P.width + px;
-                    park = (float4 *)P.scratch + ((size_t)bi * T + k) * pxb + q;
+                    park = (Parked *)P.scratch + ((size_t)bi * T + k) * pxb + q;
                 }
             }
         }
@@ -922,18 +925,18 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     const PixelRef r = locate(q);
                     if (!r.in_frame) continue;
                     float *o = r.out;
-                    const float4 *src = (const float4 *)P.scratch + (size_t)bi * T * pxb + q;
+                    const Parked *src = (const Parked *)P.scratch + (size_t)bi * T * pxb + q;
                     V3 sum = mk(o[0], o[1], o[2]);
                     uint32_t kk = 0;
                     for (; kk + 8 <= T; kk += 8) {             // eight loads in flight, additions strictly in order
-                        float4 v[8];
+                        Parked v[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j) * pxb];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
                     }
                     for (; kk < T; ++kk) {
-                        const float4 v = src[(size_t)kk * pxb];
+                        const Parked v = src[(size_t)kk * pxb];
                         sum = sum + mk(v.x, v.y, v.z);
                     }
                     o[0] = sum.x;
@@ -947,15 +950,15 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 const PixelRef r = locate(q);
                 const bool owner = jl == 0 && r.in_frame;
                 float *o = r.out;
-                const float4 *src = (const float4 *)P.scratch + (size_t)bi * T * pxb + q;
+                const Parked *src = (const Parked *)P.scratch + (size_t)bi * T * pxb + q;
                 V3 sum = mk(0.0f, 0.0f, 0.0f);
                 if (owner) sum = mk(o[0], o[1], o[2]);
                 for (uint32_t kk = 0; kk < T; kk += 8 * J) {
-                    float4 v[8];
+                    Parked v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const uint32_t k2 = kk + (uint32_t)u * J + jl;
-                        v[u] = k2 < T ? src[(size_t)k2 * pxb] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        v[u] = k2 < T ? src[(size_t)k2 * pxb] : Parked{0.0f, 0.0f, 0.0f};
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u)

@@ -317,11 +317,11 @@ def test_one_deep_call_equals_many_shallow_calls(bendy):
 def test_render_deeper_than_the_scratch_is_split_into_launches(bendy, oracle):
     """A render whose parked samples would not fit the scratch cap is issued as several launches over consecutive
     sample ranges (bt_api.cpp); bt_tuning.scratch_cap_bytes shrinks the cap so that 40 samples need 4 launches
-    (12+12+12+4).  Parking pinned to HBM: sample values that stay in LDS need no scratch at all."""
+    (12+12+12+4), pinned to the block queue."""
     w, h, spp = 64, 48, 40
-    buf, stats, _ = gpu_render(bendy, "volume", w, h, spp, tuning={"scratch_cap_bytes": 64 * 48 * 16 * 12, "park": 0})
+    buf, stats, _ = gpu_render(bendy, "volume", w, h, spp, tuning={"scratch_cap_bytes": 64 * 48 * 12 * 12, "queue": 1})
     it, seg = oracle_render(oracle, "volume", w, h, spp)
-    assert stats.launches == 4 and 0 < stats.scratch_bytes <= 64 * 48 * 16 * 12
+    assert stats.launches == 4 and 0 < stats.scratch_bytes <= 64 * 48 * 12 * 12        # 12 B per parked sample
     assert stats.slices > 1 and stats.segments == seg and stats.samples == w * h * spp
     assert np.array_equal(buf.numpy(), it)
 
@@ -583,7 +583,7 @@ def test_streaming_queue_full_size_equals_block_queue(bendy):
     no scratch (LDS) or a ring of ~100 MB (HBM) instead of 2 GB."""
     for name in ("scene", "volume"):
         a, sa, _ = gpu_render(bendy, name, 1920, 1080, 64, tuning={"queue": 1})
-        assert sa.parked_bytes >= 1920 * 1080 * 64 * 16                   # 16 B per sample (edge tiles padded)
+        assert sa.parked_bytes >= 1920 * 1080 * 64 * 12                   # 12 B per sample (edge tiles padded)
         for park in (1, 0):
             b_, sb, _ = gpu_render(bendy, name, 1920, 1080, 64, tuning={"queue": 2, "park": park})
             assert sb.segments == sa.segments and np.array_equal(a.numpy(), b_.numpy())
