@@ -588,3 +588,26 @@ def test_streaming_queue_full_size_equals_block_queue(bendy):
             b_, sb, _ = gpu_render(bendy, name, 1920, 1080, 64, tuning={"queue": 2, "park": park})
             assert sb.segments == sa.segments and np.array_equal(a.numpy(), b_.numpy())
             assert sb.scratch_bytes == 0 if sb.parked_bytes == 0 else sb.scratch_bytes < 256 * 1024 * 1024
+
+
+# ---- the exchange step behind the C ABI (bt_comm_*): RCCL at world 1 on the single GPU ------------------------------
+def test_rccl_abi_exchange_world_1(bendy, oracle):
+    """bt_comm_unique_id / bt_comm_init / bt_exchange_frame_device (include/bendy_hip.h): ncclAllGather + un-permute
+    through the library's own run-time binding of librccl.so.1.  One rank is all a one-GPU box allows; the N > 1 layout
+    is covered on CPU (tests/test_multiproc_gloo.py) and by bench.py --backend rccl-abi on the driver's 8-GPU node."""
+    import torch
+    w, h, spp = 150, 75, 6
+    sc, cam = gpu_scene(bendy, "cornell2", w, h)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    shard = bendy.new_shard(w, h, 1)
+    tr.render_shard(sc, cam, bendy.RenderConfig.with_samples(spp), shard, w, h, 0, 1)
+    comm = bendy.Comm(0, 1, bendy.Comm.unique_id())
+    gathered = torch.empty_like(shard)
+    out = bendy.Buffer.new(w, h)
+    comm.exchange(shard, gathered, out)
+    torch.cuda.synchronize()
+    comm.close()
+    it, _ = oracle_render(oracle, "cornell2", w, h, spp)
+    assert torch.equal(gathered, shard) and np.array_equal(out.numpy(), it)
+    with pytest.raises(bendy.BendyError):
+        bendy.Comm(3, 2, b"\0" * 128)           # rank >= world

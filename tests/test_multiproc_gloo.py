@@ -23,7 +23,7 @@ from helpers import oracle_render, shard_from_frame, unshard_numpy
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-w, h, spp = 72, 40, 2          # 5 x 3 tiles, not divisible by 2: one padded tile
+w, h, spp = [int(v) for v in os.environ["BT_TEST_FRAME"].split("x")]     # e.g. 72x40x2: 5 x 3 tiles, one padded tile at world 2
 full, _ = oracle_render(o, "scene", w, h, spp, threads=2)
 owner = b.tile_owner_map(w, h, world)
 # this rank only keeps the pixels of the tiles it owns
@@ -57,15 +57,18 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_tile_shard_allgather(tmp_path):
+@pytest.mark.parametrize("world,frame", [(2, "72x40x2"), (3, "100x50x2")])
+def test_gloo_tile_shard_allgather(tmp_path, world, frame):
+    """world 2: 15 tiles, one padded slot; world 3: 7 x 4 = 28 tiles (ragged right and bottom edge), 10 slots per rank with
+    two padded ones -- the strong-scaling layout of bench.py --scaling strong on a frame that does not divide evenly."""
     import subprocess
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1")
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1", BT_TEST_FRAME=frame)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=280)[0] for p in procs]

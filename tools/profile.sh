@@ -1,17 +1,30 @@
 #!/bin/bash
-# Profiling recipe for the GPU box (run via gpurun).  Kernel trace + stats in one run, each PMC
-# group in its own run (gpurun refuses --pmc combined with API traces).
-set -e
+# Profiling recipe for the GPU box (run via gpurun):  tools/profile.sh <tag> [commit]
+#   1. rocprofv3 --kernel-trace --stats over `python3 bench.py` (the bench's own command line)  -> kernel_stats.csv
+#   2. tools/pmc_collect.py for every workload: --pmc passes, one counter group per run (gpurun refuses --pmc together
+#      with API traces)                                                                       -> pmc_<workload>.json
+#   3. profiles/pmc_live.json = the summaries bench.py quotes when it cannot measure live, stamped with the source hash
+#      (tools/pmc_collect.py source_hash) and, when given, the commit (the GPU box has no .git: pass `git rev-parse HEAD`)
+# Everything lands in gpurun_out/prof_<tag>/; copy what should be judged into profiles/<tag>/.
 export TMPDIR=/tmp
-TAG=${1:-r01}
+TAG=${1:-r02}; COMMIT=${2:-unknown}
+cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
-BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq.log 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o pmc -- $BENCH > $OUT/pmc_sq2.log 2>&1 || true
-find $OUT -name "*.csv" | head -50
-python3 tools/summarize_prof.py $OUT $OUT/summary
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/bench_under_trace.log 2>$OUT/trace.err || tail -3 $OUT/trace.err
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+for wl in C3 C2 C4 cornell1080 cloud1080; do
+  python3 tools/pmc_collect.py --workload $wl --passes fetch,write,sq,classes,waits --commit $COMMIT --out $OUT/pmc_$wl.json > /dev/null 2>$OUT/pmc_$wl.err || { echo "pmc $wl failed"; tail -3 $OUT/pmc_$wl.err; }
+done
+python3 - <<PY
+import json, glob, os
+out = {}
+for f in sorted(glob.glob("$OUT/pmc_*.json")):
+    d = json.load(open(f)); out[d["workload"]] = d
+json.dump(out, open("$OUT/pmc_live.json", "w"), indent=1)
+for w, d in out.items():
+    x = d["derived"]
+    print(f"{w:12s} sha {d['source_sha']} kernel {d['cli']['kernel_ms_under_profiler']:.3f} ms (under the profiler)  VALU/SIMD-cycle {x['valu_per_simd_cycle']:.3f}  lanes {x['lanes_active']:.3f}  "
+          f"weighted {x.get('valu_issue_weighted_frac', 0):.3f}  scalar/CU-cycle {x['scalar_per_cu_cycle']:.3f}  HBM {x['hbm_bytes']/1e9:.3f} GB")
+PY
+head -5 $OUT/kernel_stats.csv
