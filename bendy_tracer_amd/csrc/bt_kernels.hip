@@ -88,8 +88,16 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // VOLS = false: no sphere carries a volume (scene.json, the Cornell boxes): the march and Volume::shade drop out.
 // QMODE: 0 = a lane owns a pixel; 1 = block queue (SLICED: a workgroup owns one pixel block, parks in HBM scratch); 2 = the
 // streaming queue (STREAM): a persistent workgroup walks its pixel blocks one after the other, see "streaming" below.
+#ifndef BT_NUM_SGPR
+#define BT_NUM_SGPR 0              // > 0: cap the kernels' SGPRs (A/B knob: <= 96 allows a seventh wave per SIMD on gfx950)
+#endif
+#if BT_NUM_SGPR > 0
+#define BT_SGPR_ATTR __attribute__((amdgpu_num_sgpr(BT_NUM_SGPR)))
+#else
+#define BT_SGPR_ATTR
+#endif
 template <int OUTPUT, bool LENS, int QMODE, bool RECTS, bool VOLS>
-__global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : BT_WAVES_PER_SIMD)) void bt_render_kernel(BtLaunch P) {
+__global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : BT_WAVES_PER_SIMD)) BT_SGPR_ATTR void bt_render_kernel(BtLaunch P) {
     constexpr bool SLICED = QMODE != 0;    // samples come from a work queue and are parked for the ordered sum
     constexpr bool STREAM = QMODE == 2;
     extern __shared__ __align__(16) unsigned char smem[];
