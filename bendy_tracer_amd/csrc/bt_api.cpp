@@ -386,6 +386,19 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     P.stream = 0;
     P.table_lds_bytes = (uint32_t)s->flat.lds_bytes();
     size_t lds_bytes = s->flat.lds_bytes();
+    {
+        // scenes with volumes: the BtVolBox table behind the scene tables; density maps whose bounds tests cannot fire
+        bool real_volumes = false, safe = true;
+        for (const BtPrim &R : s->flat.prims) real_volumes = real_volumes || R.volume >= 0;
+        for (const BtVolume &v : s->flat.volumes)
+            safe = safe && v.width >= 1 && v.height >= 1 && v.depth >= 1 && v.size.x >= 0.0f && v.size.y >= 0.0f && v.size.z >= 0.0f &&
+                   std::ceil(v.size.x) <= (float)(v.width - 1) && std::ceil(v.size.y) <= (float)(v.height - 1) &&
+                   std::ceil(v.size.z) <= (float)(v.depth - 1);
+        P.vols_safe = safe ? 1 : 0;
+        P.vbox_lds_bytes = real_volumes ? (uint32_t)(sizeof(BtVolBox) * s->flat.prims.size()) : 0u;
+        if (lds_bytes + P.vbox_lds_bytes > 32 * 1024) P.vbox_lds_bytes = 0;          // big scenes keep the per-step arithmetic
+        lds_bytes += P.vbox_lds_bytes;
+    }
     // the launch should hold >= 4 x 20 waves per CU (tuned on the MI355X's 256 CUs as "4 * 5120 waves", round 1d)
     const uint64_t wave_slots = (uint64_t)s->n_cu * 20;
     auto ensure_scratch = [&](uint64_t need) -> bool {
@@ -428,7 +441,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         const uint32_t T = (uint32_t)T_all;
         // ring: four slots; in LDS when a unit of >= 64 items and >= ~6 items per lane in flight fit beside the tables
         const uint32_t R = tune.ring_slots ? tune.ring_slots : 4;
-        const int64_t lds_budget = (int64_t)(160 * 1024 - 2048) / (tune.workgroups_per_cu ? tune.workgroups_per_cu : occ) - (int64_t)lds_bytes - 3 * 64 * 4 - 64;
+        const int64_t lds_budget = (int64_t)(160 * 1024 - 2048) / (tune.workgroups_per_cu ? tune.workgroups_per_cu : occ) - (int64_t)lds_bytes - 3 * 64 * 4 - 64;   // lds_bytes: tables + volume boxes
         const uint32_t tc_lds = lds_budget > 0 ? (uint32_t)(lds_budget / (int64_t)(R * pxb * 12)) : 0u;
         bool ring_lds = tc_lds * pxb >= 256 && tc_lds >= 1;
         if (tune.park >= 0) ring_lds = tune.park == 1 && tc_lds >= 1 && tc_lds * pxb >= 64;

@@ -646,6 +646,43 @@ BT_DEV BlockPixel block_pixel(uint32_t sub, uint32_t q, uint32_t pxb) {
     return r;
 }
 
+// DensityMap::sample for maps whose bounds tests cannot fire (BtLaunch::vols_safe): density_sample() without the clamp of
+// negative indices and the width / height / depth tests of density_at() -- cx = clamp(coord, 0, 1) * size lies in
+// [0, size] (NaN clamps to 0), so floor and ceil lie in [0, dim - 1].  Same fetches, same lerps, same bits.
+BT_DEV float density_sample_safe(const BtVolume &vol, const float *density, V3 coord) {
+    const float cx = fminf(fmaxf(coord.x, 0.0f), 1.0f) * vol.size.x;
+    const float cy = fminf(fmaxf(coord.y, 0.0f), 1.0f) * vol.size.y;
+    const float cz = fminf(fmaxf(coord.z, 0.0f), 1.0f) * vol.size.z;
+    const float fx = floorf(cx), fy = floorf(cy), fz = floorf(cz);
+    const float tx = cx - truncf(cx), ty = cy - truncf(cy), tz = cz - truncf(cz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz, x1 = (int)ceilf(cx), y1 = (int)ceilf(cy), z1 = (int)ceilf(cz);
+    const float *d = density + vol.offset;
+    const int r00 = (z0 * vol.height + y0) * vol.width, r01 = (z0 * vol.height + y1) * vol.width;
+    const int r10 = (z1 * vol.height + y0) * vol.width, r11 = (z1 * vol.height + y1) * vol.width;
+    const float a = lerpf(d[r00 + x0], d[r00 + x1], tx), b = lerpf(d[r01 + x0], d[r01 + x1], tx);
+    const float z_lo = lerpf(a, b, ty);
+    const float c = lerpf(d[r10 + x0], d[r10 + x1], tx), e = lerpf(d[r11 + x0], d[r11 + x1], tx);
+    const float z_hi = lerpf(c, e, ty);
+    return lerpf(z_lo, z_hi, tz);
+}
+// march_density() through the BtVolBox table: rel / size by div_refined() -- the same bits as the IEEE division whenever
+// no intermediate leaves the normal range, which holds for 2^-20 <= size <= 2^20 (box.ok) and |rel| = 0 or within
+// [2^-60, 2^60]; a wave in which any lane falls outside takes the exact path below.
+BT_DEV float march_density_box(const BtLaunch &P, const SceneLds &S, int vol_index, const BtVolBox &box, V3 pos) {
+    const BtVolume &vol = S.volumes[vol_index];
+    const V3 rel = pos - mk(box.bmin), size = mk(box.size);
+    const float ax = fabsf(rel.x), ay = fabsf(rel.y), az = fabsf(rel.z);
+    const bool in_range = (box.ok != 0.0f) & (ax == 0.0f || (ax >= 0x1p-60f && ax <= 0x1p60f)) &
+                          (ay == 0.0f || (ay >= 0x1p-60f && ay <= 0x1p60f)) & (az == 0.0f || (az >= 0x1p-60f && az <= 0x1p60f));
+    V3 coord;
+    if (__ballot(!in_range) == 0ull) {
+        coord = mk(div_refined(rel.x, size.x, box.rcp.x), div_refined(rel.y, size.y, box.rcp.y), div_refined(rel.z, size.z, box.rcp.z));
+    } else {
+        coord = mk(rel.x / size.x, rel.y / size.y, rel.z / size.z);
+    }
+    return P.volume_step * (P.vols_safe ? density_sample_safe(vol, S.density, coord) : density_sample(vol, S.density, coord));
+}
+
 // The scatter probability of one march step, Volume::shade's `volume_step * density.sample(coord)` (volume.rs:26-35)
 // with coord = (pos - bbox.min) / bbox.size of the sphere's bounding box (sphere.rs:35-38).
 BT_DEV float march_density(const BtLaunch &P, const SceneLds &S, int vol_index, V3 prim_c, float prim_radius, V3 pos) {

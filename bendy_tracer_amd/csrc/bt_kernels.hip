@@ -160,7 +160,25 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     }
     // STREAM: behind the scene tables (BtLaunch::table_lds_bytes) the running sums of the block being summed and, when it
     // fits, the ring of parked sample values
-    float *const s_accum = (float *)(smem + P.table_lds_bytes);
+    BtVolBox *const vbox = (BtVolBox *)(smem + P.table_lds_bytes);      // VOLS builds: bt_types.h BtVolBox, one per primitive
+    if (VOLS && P.vbox_lds_bytes) {
+        for (int i = threadIdx.x; i < P.n_prims; i += blockDim.x) {
+            const BtPrim &R = P.prims[i];
+            BtVolBox bx;
+            const V3 c = mk(R.c), hsz = mk(R.radius, R.radius, R.radius);
+            const V3 bmin = c - hsz, bmax = c + hsz, size = bmax - bmin;            // sphere.rs:35-38, volume.rs:29-31
+            bx.bmin.x = bmin.x; bx.bmin.y = bmin.y; bx.bmin.z = bmin.z;
+            bx.size.x = size.x; bx.size.y = size.y; bx.size.z = size.z;
+            bx.rcp.x = refined_rcp(size.x); bx.rcp.y = refined_rcp(size.y); bx.rcp.z = refined_rcp(size.z);
+            const bool ok = size.x >= 0x1p-20f && size.x <= 0x1p20f && size.y >= 0x1p-20f && size.y <= 0x1p20f &&
+                            size.z >= 0x1p-20f && size.z <= 0x1p20f;
+            bx.ok = ok ? 1.0f : 0.0f;
+            bx.pad0 = bx.pad1 = 0.0f;
+            vbox[i] = bx;
+        }
+        __syncthreads();
+    }
+    float *const s_accum = (float *)(smem + P.table_lds_bytes + P.vbox_lds_bytes);
     float *const ring_l = s_accum + 3 * 64;
 
     // ---- tile / pixel mapping ----
@@ -372,8 +390,6 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         unsigned long long act;
         asm volatile("s_mov_b64 %0, exec" : "=s"(act));
         const int first = __ffsll((long long)act) - 1;
-        const uint32_t n_act = (uint32_t)__popcll(act);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
         for (;;) {
             // The protocol words s_summed / s_ready / s_done live in LDS and every access to them is ordered against the
             // next by a sequentially consistent LDS fence: "my ready bit is set" must be visible before this wave looks at
@@ -396,8 +412,14 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             const uint32_t Tcu = chunk == n_chunks - 1u ? last_T : chunk_T;
             const bool first_chunk = chunk == 0u, last_chunk = chunk == n_chunks - 1u;
 
-            for (uint32_t q = rank; q < pxb; q += n_act) {
-
+            // The lanes that execute the pixel loop, read where it starts: the compiler structures this for (;;) as a loop with
+            // divergent exits and may have taken lanes out of EXEC by the second trip (seen on the MI355X: the mask read at
+            // the top of the function differed in ~1 % of the sums, and the pixels of the missing ranks were skipped).
+            unsigned long long act2;
+            asm volatile("s_mov_b64 %0, exec" : "=s"(act2));
+            const uint32_t n_act2 = (uint32_t)__popcll(act2);
+            const uint32_t rank2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act2, 0u));
+            for (uint32_t q = rank2; q < pxb; q += n_act2) {
                 const PixelRef pr = locate_stream(b, q);
                 V3 sum = mk(0.0f, 0.0f, 0.0f);
                 if (first_chunk) {
@@ -463,6 +485,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         int pobject = -1, mat_index = 0, vol_index = 0;
         V3 prim_c = mk(0, 0, 0);
         float prim_radius = 0.0f;
+        int hit_prim = 0;
 
         BT_LS(1, __ballot(!pending && !(VOTE && held)));
         if (!pending) {
@@ -514,6 +537,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 pobject = pl.kind_object >> 8;
                 prim_c = mk(pl.c);
                 prim_radius = pl.radius;
+                hit_prim = h.prim;
                 hit_depth = LENS ? h.t + travelled : h.t;
                 pos = ro + rd * h.t;
                 bool vol_face = false;
@@ -843,7 +867,8 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 dir = base + v * M.roughness;
             } else if (VOLS) {
                 // ---- Volume::shade (volume.rs:26-60) ----
-                const float density = march_density(P, S, vol_index, prim_c, prim_radius, pos);
+                const float density = P.vbox_lds_bytes ? march_density_box(P, S, vol_index, vbox[hit_prim], pos)
+                                                       : march_density(P, S, vol_index, prim_c, prim_radius, pos);
                 if (density >= 1.0f || bernoulli(u.x, density)) {
                     if (inside) new_o = pos - (rd * P.volume_step) * u24(u.y);
                     dir = v;

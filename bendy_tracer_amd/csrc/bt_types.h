@@ -92,6 +92,13 @@ struct BtRectLA {
 };
 static_assert(sizeof(BtRectLA) == 80, "BtRectLA must be 80 bytes");
 
+struct BtVolBox {       // LDS only
+    BtV3 bmin; float ok;    // bbox.min; ok != 0: size components within [2^-20, 2^20] (div_refined's range)
+    BtV3 size; float pad0;  // bbox.max - bbox.min
+    BtV3 rcp;  float pad1;  // refined_rcp(size)
+};
+static_assert(sizeof(BtVolBox) == 48, "BtVolBox must be 48 bytes");
+
 // Per-lane (divergent) lookups after the loop read this 32-byte digest from LDS.
 struct BtPrimLite {
     BtV3 c;             // sphere centre | rect world normal
@@ -205,6 +212,12 @@ struct BtLaunch {
     uint32_t *block_counter;          // next unclaimed pixel block of the launch (zeroed before every launch)
     uint32_t tiles_x_magic;           // floor(2^32 / tiles_x) + 1: tile / tiles_x = umulhi(tile, magic), fixed up by one step
     uint32_t table_lds_bytes;         // bytes of the scene tables at the start of dynamic LDS
+    // Scenes with volumes: behind the tables one BtVolBox per primitive (48 B; filled by the kernel's prologue for the
+    // spheres that carry a volume): the bounding box Volume::shade divides by (volume.rs:26-35, sphere.rs:35-38) and the
+    // refined reciprocal of its size, so that the three divisions of every march step share div_refined()'s reciprocal.
+    uint32_t vbox_lds_bytes;          // 48 * n_prims, or 0
+    int32_t vols_safe;                // 1: every density map has dims >= 1 and 0 <= ceil(size) <= dim - 1: DensityMap::index's
+                                      // bounds tests (volume.rs:119-134) cannot fire for a clamped coordinate
     // Phase voting (bt_kernels.hip, sphere-only builds): every iteration the wave runs EITHER the camera event OR the
     // scatter / volume events, whichever more of its lanes want; the others keep what they have (no ray yet, or their
     // hit) for the next iteration, at most phase_vote iterations in a row (0 = off).  Scheduling only: every lane

@@ -611,3 +611,24 @@ def test_rccl_abi_exchange_world_1(bendy, oracle):
     assert torch.equal(gathered, shard) and np.array_equal(out.numpy(), it)
     with pytest.raises(bendy.BendyError):
         bendy.Comm(3, 2, b"\0" * 128)           # rank >= world
+
+
+def test_volume_fast_paths_and_their_fallbacks(bendy, oracle):
+    """Round 2's march shortcuts (BtVolBox + div_refined for the three divisions of Volume::shade, DensityMap::sample
+    without the bounds tests) apply to well-formed scenes only; a density map whose `size` exceeds dim - 1 (the reference
+    would assert, the oracle returns 0 there) and a volume sphere far outside the reciprocal's range take the exact code.
+    All three must give the oracle's bits."""
+    import gzip
+    doc = json.loads(gzip.open(scene_path("volume")).read())
+    vol_key = next(k for k, v in doc["data"]["collection"].items() if "Volume" in v["inner"])
+    sph_key = next(k for k, v in doc["objects"]["collection"].items()
+                   if isinstance(v["inner"], dict) and "Sphere" in v["inner"] and v["inner"]["Sphere"]["volume"] is not None)
+    variants = {"as bundled": doc}
+    unsafe = json.loads(json.dumps(doc))
+    unsafe["data"]["collection"][vol_key]["inner"]["Volume"]["DensityMap"]["size"] = [9.5, 7.0, 3.0]
+    variants["size beyond the map"] = unsafe
+    huge = json.loads(json.dumps(doc))
+    huge["objects"]["collection"][sph_key]["inner"]["Sphere"]["radius"] = 2.0e6        # bbox size 4e6 > 2^20
+    variants["volume sphere outside div_refined's range"] = huge
+    for label, d in variants.items():
+        _compare_json_scene(bendy, oracle, json.dumps(d), 96, 64, 6)
