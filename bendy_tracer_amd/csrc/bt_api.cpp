@@ -508,7 +508,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             const uint64_t T = (uint64_t)chunk * nn;
             uint32_t tpw = 1;
             while (P.slices == 1 && !P.any_rects && !P.any_volumes && tpw < 4 && 256ull * (2 * tpw) * T <= 4096 &&
-                   (uint64_t)grid / (2 * tpw) >= 2 * (uint64_t)s->n_cu * 7)
+                   (uint64_t)grid / (2 * tpw) >= 2 * (uint64_t)s->n_cu * 7)   /* >= two rounds of 7 workgroups per CU */
                 tpw *= 2;
             if (tune.tiles_per_wg && P.slices == 1) tpw = tune.tiles_per_wg;
             P.tiles_per_wg = (int32_t)tpw;

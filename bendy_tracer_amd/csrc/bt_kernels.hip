@@ -65,8 +65,8 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #define BT_WAVES_PER_SIMD 6
 #endif
 #ifndef BT_WAVES_PER_SIMD_RECTS
-#define BT_WAVES_PER_SIMD_RECTS 7      // scenes with rects are TRACE-bound, their builds gain from a seventh wave (72 VGPRs):
-#endif                                 // Cornell 12.05 -> 11.6 ms, profiles/r01g/ab_w567_vote.log
+#define BT_WAVES_PER_SIMD_RECTS 6      // round 1 built the rect scenes for a seventh wave (72 VGPRs, 64 B of spills); with round 2's cheaper
+#endif                                 // TRACE the spills cost more than the wave hides: Cornell 7.76 -> 7.66 ms at 6 (profiles/r02l/ab_waves_r6_r5v5.log)
 #ifndef BT_WAVES_PER_SIMD_LENS
 #define BT_WAVES_PER_SIMD_LENS 6       // lens builds: 80 VGPRs + ~100 B of scratch per lane still beat 4 waves without
 #endif                                 // scratch (665 -> 719 Msamples/s, profiles/r01g/ab_lens_waves.log)
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             l.kind_object = (R.kind & BT_PRIM_SHAPE_MASK) | (R.object << 8);
             l.material = R.material;
             l.volume = R.volume;
-            l.pad = 0;
+            l.rcp_radius = ((R.kind & BT_PRIM_SHAPE_MASK) == BT_PRIM_SPHERE && R.radius >= 0x1p-20f && R.radius <= 0x1p20f) ? refined_rcp(R.radius) : 0.0f;
             lite[i] = l;
         }
         for (int i = threadIdx.x; i < P.n_materials; i += blockDim.x) mats[i] = P.materials[i];
@@ -545,8 +545,17 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     inside = true;
                     vol_face = true;
                 } else if (!RECTS || pshape == BT_PRIM_SPHERE) { // generate_surface_manifold (sphere.rs:85-119)
+                    // normal = (position - centre) / radius (sphere.rs:95-99): div_refined() with the sphere's refined
+                    // reciprocal -- the IEEE quotient's bits while every operand is 0 or within [2^-60, 2^60] (it is ~radius
+                    // here); a wave with a lane outside that range divides exactly
                     V3 nrm = pos - prim_c;
-                    nrm = mk(nrm.x / pl.radius, nrm.y / pl.radius, nrm.z / pl.radius);
+                    const float nax = fabsf(nrm.x), nay = fabsf(nrm.y), naz = fabsf(nrm.z), rr = pl.rcp_radius;
+                    const bool in_range = (rr != 0.0f) & (nax == 0.0f || (nax >= 0x1p-60f && nax <= 0x1p60f)) &
+                                          (nay == 0.0f || (nay >= 0x1p-60f && nay <= 0x1p60f)) & (naz == 0.0f || (naz >= 0x1p-60f && naz <= 0x1p60f));
+                    if (__ballot(!in_range) == 0ull)
+                        nrm = mk(div_refined(nrm.x, pl.radius, rr), div_refined(nrm.y, pl.radius, rr), div_refined(nrm.z, pl.radius, rr));
+                    else
+                        nrm = mk(nrm.x / pl.radius, nrm.y / pl.radius, nrm.z / pl.radius);
                     front = dot(rd, nrm) < 0.0f;
                     normal = front ? nrm : -nrm;
                     vol_face = VOLS && pl.volume >= 0;

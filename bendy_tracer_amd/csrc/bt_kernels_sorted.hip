@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 5) void bt_render_sorted_kernel(BtLaunch P) {
             l.kind_object = (R.kind & BT_PRIM_SHAPE_MASK) | (R.object << 8);
             l.material = R.material;
             l.volume = R.volume;
-            l.pad = 0;
+            l.rcp_radius = 0.0f;
             lite[i] = l;
         }
         for (int i = threadIdx.x; i < P.n_materials; i += blockDim.x) mats[i] = P.materials[i];

@@ -106,7 +106,8 @@ struct BtPrimLite {
     int32_t kind_object;  // shape | object << 8
     int32_t material;
     int32_t volume;
-    int32_t pad;
+    float rcp_radius;     // bt_kernels.hip only: refined_rcp(radius) for spheres with 2^-20 <= radius <= 2^20, else 0 (bt_device.hpp
+                          // div_refined: the three divisions of Sphere's normal, sphere.rs:95-99, share it)
 };
 
 enum { BT_MAT_FLAT = 0, BT_MAT_DIFFUSE = 1, BT_MAT_METALLIC = 2, BT_MAT_GLASS = 3, BT_MAT_EMISSIVE = 4 };
