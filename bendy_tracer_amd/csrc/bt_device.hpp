@@ -62,6 +62,23 @@ BT_DEV void sincos_bt(float x, float &s, float &c) {
     c = ((q + 1) & 2) ? -co : co;
 }
 
+// sincos_bt() for a wave whose arguments all reduce with k = 0 (|x| <= pi/4: the camera's frustum angles): the three
+// Cody-Waite steps are fmaf(+-0, c, r) = r and the quadrant fix-up is the identity, so they are skipped -- same bits.
+// Any lane with k != 0 sends the whole wave through sincos_bt().
+BT_DEV void sincos_small_bt(float x, float &s, float &c) {
+    const float k = __builtin_rintf(x * 0.636619772f);
+    if (__ballot(k != 0.0f) != 0ull) {
+        sincos_bt(x, s, c);
+        return;
+    }
+    const float r = x + 0.0f, r2 = r * r;          // fmaf(+-0, c, x) is x, except that it turns x = -0 into +0: so does x + 0
+    const float ps = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    s = __builtin_fmaf(ps * r2, r, r);
+    const float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2,
+                                    4.166664568298827e-2f);
+    c = __builtin_fmaf(pc, r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+}
+
 // ---- Philox4x32-10 (numerics contract N6) --------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
 #ifndef BT_PHILOX_ROUNDS

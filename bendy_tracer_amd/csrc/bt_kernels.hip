@@ -790,8 +790,8 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             const float yrot = C->xfov * 0.5f * -uu;
             const float xrot = C->yfov * 0.5f * -vv;
             float sy, cy, sx, cx;
-            sincos_bt(yrot, sy, cy);
-            sincos_bt(xrot, sx, cx);
+            sincos_small_bt(yrot, sy, cy);              // |angle| <= fov / 2: k = 0 for every frustum below 90 degrees
+            sincos_small_bt(xrot, sx, cx);
             const V3 d_cam = mk(-(cx * sy), sx, -(cx * cy));
             // Affine3A * Ray: origin = translation + 0; direction = normalize(normalize_or_zero(M*d)),
             // the outer normalize being the shared one below
