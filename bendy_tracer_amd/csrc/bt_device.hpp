@@ -34,9 +34,48 @@ BT_DEV V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
 BT_DEV V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
 BT_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 BT_DEV float len2(V3 a) { return dot(a, a); }
-BT_DEV V3 normalize(V3 a) { float rl = 1.0f / sqrtf(len2(a)); return a * rl; }
+// sqrtf(x) and 1.0f / sqrtf(x), bit for bit, in fewer issue slots.  hipcc expands an IEEE square root into v_sqrt_f32
+// (1 ulp), the two neighbours s -/+ 1 ulp tried against the residuals x - s_down s, x - s_up s, and around that a 2^32
+// pre-scaling of inputs below 2^-96 plus a pass-through of +-0 / inf (AMDGPU lowerFSQRTF32); an IEEE division by s is
+// v_rcp_f32, two Newton steps, quotient, two residual corrections, and around those v_div_scale / v_div_fmas /
+// v_div_fixup (refined_rcp() / div_refined() below).  When every live lane's x lies in [2^-96, 2^96) -- one integer
+// compare and a wave-uniform branch -- the scaling, the pass-through and the fix-up are no-ops: what is left is the
+// core sequence, written out here; any other wave takes the compiler's expansion.  (s in [2^-48, 2^48): no
+// intermediate of 1/s leaves the normal range, and 1 * r is exact, so the quotient step drops out.)
+#ifndef BT_FAST_SQRT
+#define BT_FAST_SQRT 1
+#endif
+BT_DEV bool sqrt_core_ok(float x) {
+    return __builtin_amdgcn_ballot_w64((__float_as_uint(x) - 0x0f800000u) >= (0x6f800000u - 0x0f800000u)) == 0ull;
+}
+BT_DEV float sqrt_core(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+    s = rd <= 0.0f ? sd : s;
+    return ru > 0.0f ? su : s;
+}
+BT_DEV float sqrt_bt(float x) {
+#if BT_FAST_SQRT
+    if (sqrt_core_ok(x)) return sqrt_core(x);
+#endif
+    return sqrtf(x);
+}
+BT_DEV float rsqrt_bt(float x) {                    // 1.0f / sqrtf(x)
+#if BT_FAST_SQRT
+    if (sqrt_core_ok(x)) {
+        const float s = sqrt_core(x);
+        const float r0 = __builtin_amdgcn_rcpf(s);
+        const float r = __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
+        const float m2 = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
+        return __builtin_fmaf(__builtin_fmaf(-s, m2, 1.0f), r, m2);
+    }
+#endif
+    return 1.0f / sqrtf(x);
+}
+BT_DEV V3 normalize(V3 a) { float rl = rsqrt_bt(len2(a)); return a * rl; }
 BT_DEV V3 normalize_or_zero(V3 a) {
-    float rl = 1.0f / sqrtf(len2(a));
+    float rl = rsqrt_bt(len2(a));
     bool ok = (rl > 0.0f) && (rl < __builtin_inff());
     return ok ? a * rl : mk(0.0f, 0.0f, 0.0f);
 }
@@ -112,7 +151,7 @@ BT_DEV V3 reflect(V3 v, V3 n) { return v - n * (2.0f * dot(v, n)); }
 BT_DEV V3 refract(V3 v, V3 n, float ior) {
     float cos_theta = fminf(dot(-v, n), 1.0f);
     V3 perp = (n * cos_theta + v) * ior;
-    V3 parallel = n * -sqrtf(fabsf(1.0f - len2(perp)));
+    V3 parallel = n * -sqrt_bt(fabsf(1.0f - len2(perp)));
     return perp + parallel;
 }
 BT_DEV float fresnel(V3 v, V3 n, float ior) {
@@ -137,8 +176,8 @@ BT_DEV V3 unit_sphere(const BtLaunch &P, uint32_t x1, uint32_t x2) {
     float r1 = uniform_sample(x1, 0.0f, P.tau_scale), r2 = uniform_sample(x2, 0.0f, P.one_scale);
     float s, c;
     sincos_bt(r1, s, c);
-    float x = c * 2.0f * sqrtf(r2 * (1.0f - r2));
-    float y = s * 2.0f * sqrtf(r2 * (1.0f - r2));
+    float x = c * 2.0f * sqrt_bt(r2 * (1.0f - r2));
+    float y = s * 2.0f * sqrt_bt(r2 * (1.0f - r2));
     float z = 1.0f - 2.0f * r2;
     return mk(x, y, z);
 }
@@ -148,8 +187,8 @@ BT_DEV V3 unit_hemisphere(const BtLaunch &P, V3 normal, uint32_t x1, uint32_t x2
     float r1 = uniform_sample(x1, 0.0f, P.tau_scale), r2 = uniform_sample(x2, 0.0f, P.one_scale);
     float s, c;
     sincos_bt(r1, s, c);
-    float x = c * 2.0f * sqrtf(r2 * (1.0f - r2));
-    float y = s * 2.0f * sqrtf(r2 * (1.0f - r2));
+    float x = c * 2.0f * sqrt_bt(r2 * (1.0f - r2));
+    float y = s * 2.0f * sqrt_bt(r2 * (1.0f - r2));
     float z = 1.0f - r2;
     return (x_axis * x + y_axis * y) + z_axis * z;
 }
@@ -159,9 +198,9 @@ BT_DEV V3 cosine(const BtLaunch &P, V3 normal, uint32_t x1, uint32_t x2) {
     float r1 = uniform_sample(x1, 0.0f, P.tau_scale), r2 = uniform_sample(x2, 0.0f, P.one_scale);
     float s, c;
     sincos_bt(r1, s, c);
-    float x = c * sqrtf(r2);
-    float y = s * sqrtf(r2);
-    float z = sqrtf(1.0f - r2);
+    float x = c * sqrt_bt(r2);
+    float y = s * sqrt_bt(r2);
+    float z = sqrt_bt(1.0f - r2);
     return (x_axis * x + y_axis * y) + z_axis * z;
 }
 
@@ -183,7 +222,7 @@ BT_DEV bool sphere_t(V3 o, V3 d, V3 c, float radius, float tmin, float tmax, flo
     float cc = len2(oc) - radius * radius;
     float disc = half_b * half_b - cc;
     if (!(disc >= 0.0f)) return false;
-    float sqrtd = sqrtf(disc);
+    float sqrtd = sqrt_bt(disc);
     float t = -half_b - sqrtd;
     if (t < tmin || t > tmax) {
         t = -half_b + sqrtd;
@@ -354,7 +393,7 @@ BT_DEV HitRec intersect_spheres(const BtLaunch &P, V3 o, V3 d, float tmin, float
             }
             const float ds = s ? disc.y : disc.x, hb = s ? half_b.y : half_b.x;
             if (!taken && ds >= 0.0f) {                                      // sphere_t()'s root selection
-                const float sqrtd = sqrtf(ds);
+                const float sqrtd = sqrt_bt(ds);
                 float t = -hb - sqrtd;
                 bool ok = !(t < tmin || t > h.t);
                 if (!ok) {
@@ -790,7 +829,7 @@ BT_DEV int lens_advance(const BtLaunch &P, V3 &x, V3 &v, LensState &st, HitRec &
                 const float hb = dot(rel, v), cc = r2 - R2, disc = hb * hb - cc;
                 float t_enter = __builtin_inff();
                 if (disc >= 0.0f) {
-                    const float te = -hb - sqrtf(disc);
+                    const float te = -hb - sqrt_bt(disc);
                     if (te > 0.0f) t_enter = te;
                 }
                 const float seg = fminf(t_enter, st.remaining);

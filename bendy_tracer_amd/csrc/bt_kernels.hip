@@ -826,11 +826,11 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             const bool is_cosine = ev == EV_DIFFUSE && !to_light;
             const bool in_frame_of_normal = is_cosine || ev == EV_METALLIC || ev == EV_GLASS;
             // UnitSphere (distr.rs:10-21), UnitHemisphere (:48-59, z = 1 - r2), Cosine (:86-97)
-            const float sq = sqrtf(is_cosine ? r2 : r2 * (1.0f - r2));
+            const float sq = sqrt_bt(is_cosine ? r2 : r2 * (1.0f - r2));
             const float lx_ = (is_cosine ? cs : cs * 2.0f) * sq;
             const float ly_ = (is_cosine ? sn : sn * 2.0f) * sq;
             float lz_ = in_frame_of_normal ? 1.0f - r2 : 1.0f - 2.0f * r2;
-            if (is_cosine) lz_ = sqrtf(1.0f - r2);
+            if (is_cosine) lz_ = sqrt_bt(1.0f - r2);
             V3 v = mk(lx_, ly_, lz_);
             if (in_frame_of_normal) {
                 V3 z_axis = normalize(normal), x_axis, y_axis;
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             } else if (ev == EV_GLASS) {                                  // :240-261
                 const float ior = front ? M.inv_ior : M.ior;
                 const float cos_theta = fminf(dot(-rd, normal), 1.0f);
-                const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                const float sin_theta = sqrt_bt(1.0f - cos_theta * cos_theta);
                 const float fr = fresnel(rd, normal, ior);
                 V3 base;
                 if (ior * sin_theta > 1.0f || bernoulli(u.x, fr))
