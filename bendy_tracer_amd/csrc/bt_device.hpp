@@ -722,14 +722,15 @@ BT_DEV float density_sample_safe(const BtVolume &vol, const float *density, V3 c
     return lerpf(z_lo, z_hi, tz);
 }
 // march_density() through the BtVolBox table: rel / size by div_refined() -- the same bits as the IEEE division whenever
-// no intermediate leaves the normal range, which holds for 2^-20 <= size <= 2^20 (box.ok) and |rel| = 0 or within
+// no intermediate leaves the normal range, which holds for 2^-20 <= size <= 2^20 (box.ok) and |rel| within
 // [2^-60, 2^60]; a wave in which any lane falls outside takes the exact path below.
 BT_DEV float march_density_box(const BtLaunch &P, const SceneLds &S, int vol_index, const BtVolBox &box, V3 pos) {
     const BtVolume &vol = S.volumes[vol_index];
     const V3 rel = pos - mk(box.bmin), size = mk(box.size);
+    // (min / max of the three magnitudes: two compares instead of nine; an exact 0 now also takes the exact path, and a
+    // NaN component, which fminf / fmaxf skip, gives NaN on either path and is clamped to 0 by the sampler)
     const float ax = fabsf(rel.x), ay = fabsf(rel.y), az = fabsf(rel.z);
-    const bool in_range = (box.ok != 0.0f) & (ax == 0.0f || (ax >= 0x1p-60f && ax <= 0x1p60f)) &
-                          (ay == 0.0f || (ay >= 0x1p-60f && ay <= 0x1p60f)) & (az == 0.0f || (az >= 0x1p-60f && az <= 0x1p60f));
+    const bool in_range = (box.ok != 0.0f) & (fminf(fminf(ax, ay), az) >= 0x1p-60f) & (fmaxf(fmaxf(ax, ay), az) <= 0x1p60f);
     V3 coord;
     if (__ballot(!in_range) == 0ull) {
         coord = mk(div_refined(rel.x, size.x, box.rcp.x), div_refined(rel.y, size.y, box.rcp.y), div_refined(rel.z, size.z, box.rcp.z));

@@ -73,6 +73,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
 #define BT_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local")   // orders LDS accesses only (lgkmcnt)
 #define BT_RING_MAX 4               // most ring slots of the streaming queue (BtLaunch::ring_slots)
+#ifndef BT_SKIP_DIR
+#define BT_SKIP_DIR 1          // a wave of pass-through march steps skips the direction sampling
+#endif
 #ifndef BT_VOTE3
 #define BT_VOTE3 0                 // 1: builds with volumes vote between three kinds of event (measured slower, profiles/r02d/ab_vote3_rejected.log)
 #endif
@@ -757,8 +760,17 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         const uint32_t w1 = ev == EV_METALLIC ? u.x : (ev == EV_GLASS ? u.y : u.z);
         const uint32_t w2 = ev == EV_METALLIC ? u.y : (ev == EV_GLASS ? u.z : u.w);
         const float r1 = uniform_sample(w1, 0.0f, P.tau_scale), r2 = uniform_sample(w2, 0.0f, P.one_scale);
-        float sn, cs;
-        sincos_bt(r1, sn, cs);
+        // Volume::shade's scatter decision (volume.rs:26-35) comes first: a march step that passes through needs no
+        // sampled direction, and a wave whose lanes all pass through skips the angular draws below altogether
+        bool vol_scatter = false;
+        if (VOLS && ev == EV_VOLUME) {
+            const float density = P.vbox_lds_bytes ? march_density_box(P, S, vol_index, vbox[hit_prim], pos)
+                                                   : march_density(P, S, vol_index, prim_c, prim_radius, pos);
+            vol_scatter = density >= 1.0f || bernoulli(u.x, density);
+        }
+        const bool wave_needs_dir = !VOLS || !BT_SKIP_DIR || __ballot(ev != EV_VOLUME || vol_scatter) != 0ull;
+        float sn = 0.0f, cs = 0.0f;
+        if (wave_needs_dir) sincos_bt(r1, sn, cs);
         BT_PROF(2);                                       // Philox + shared sin/cos
 
         V3 new_o = pos, dir = rd;
@@ -826,16 +838,19 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             const bool is_cosine = ev == EV_DIFFUSE && !to_light;
             const bool in_frame_of_normal = is_cosine || ev == EV_METALLIC || ev == EV_GLASS;
             // UnitSphere (distr.rs:10-21), UnitHemisphere (:48-59, z = 1 - r2), Cosine (:86-97)
-            const float sq = sqrt_bt(is_cosine ? r2 : r2 * (1.0f - r2));
-            const float lx_ = (is_cosine ? cs : cs * 2.0f) * sq;
-            const float ly_ = (is_cosine ? sn : sn * 2.0f) * sq;
-            float lz_ = in_frame_of_normal ? 1.0f - r2 : 1.0f - 2.0f * r2;
-            if (is_cosine) lz_ = sqrt_bt(1.0f - r2);
-            V3 v = mk(lx_, ly_, lz_);
-            if (in_frame_of_normal) {
-                V3 z_axis = normalize(normal), x_axis, y_axis;
-                orthonormal_pair(z_axis, x_axis, y_axis);
-                v = (x_axis * lx_ + y_axis * ly_) + z_axis * lz_;
+            V3 v = mk(0.0f, 0.0f, 0.0f);
+            if (wave_needs_dir) {
+                const float sq = sqrt_bt(is_cosine ? r2 : r2 * (1.0f - r2));
+                const float lx_ = (is_cosine ? cs : cs * 2.0f) * sq;
+                const float ly_ = (is_cosine ? sn : sn * 2.0f) * sq;
+                float lz_ = in_frame_of_normal ? 1.0f - r2 : 1.0f - 2.0f * r2;
+                if (is_cosine) lz_ = sqrt_bt(1.0f - r2);
+                v = mk(lx_, ly_, lz_);
+                if (in_frame_of_normal) {
+                    V3 z_axis = normalize(normal), x_axis, y_axis;
+                    orthonormal_pair(z_axis, x_axis, y_axis);
+                    v = (x_axis * lx_ + y_axis * ly_) + z_axis * lz_;
+                }
             }
 
             if (ev == EV_DIFFUSE) {
@@ -876,9 +891,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 dir = base + v * M.roughness;
             } else if (VOLS) {
                 // ---- Volume::shade (volume.rs:26-60) ----
-                const float density = P.vbox_lds_bytes ? march_density_box(P, S, vol_index, vbox[hit_prim], pos)
-                                                       : march_density(P, S, vol_index, prim_c, prim_radius, pos);
-                if (density >= 1.0f || bernoulli(u.x, density)) {
+                if (vol_scatter) {
                     if (inside) new_o = pos - (rd * P.volume_step) * u24(u.y);
                     dir = v;
                     beta = beta * mk(0.8f, 0.8f, 0.8f);
