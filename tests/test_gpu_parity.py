@@ -632,3 +632,17 @@ def test_volume_fast_paths_and_their_fallbacks(bendy, oracle):
     variants["volume sphere outside div_refined's range"] = huge
     for label, d in variants.items():
         _compare_json_scene(bendy, oracle, json.dumps(d), 96, 64, 6)
+
+
+def test_exact_math_helpers_over_all_inputs():
+    """bt_device.hpp computes sqrt, 1/sqrt, the hoisted divisions and the camera's small-angle sin/cos with the core of the
+    compiler's own IEEE expansions (sqrt_bt, rsqrt_bt, div_refined, sincos_small_bt).  tools/exact_math_check.hip compares
+    each of them on the device with the plain expression it replaces, over all 2^32 bit patterns of the argument
+    (2^32 operand pairs for the division); `make` builds it next to the library."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bendy_tracer_amd", "exact_math_check")
+    assert os.path.exists(exe), "bendy_tracer_amd/exact_math_check is not built (make -C bendy_tracer_amd/csrc)"
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    lines = [ln for ln in run.stdout.splitlines() if "mismatches" in ln]
+    assert len(lines) == 4 and all(ln.rstrip().endswith("mismatches 0") for ln in lines), run.stdout
