@@ -73,6 +73,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
 #define BT_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local")   // orders LDS accesses only (lgkmcnt)
 #define BT_RING_MAX 4               // most ring slots of the streaming queue (BtLaunch::ring_slots)
+#ifndef BT_WG_THREADS
+#define BT_WG_THREADS 256      // lanes per workgroup of the block queue (A/B knob: 64 / 128 / 256)
+#endif
 #ifndef BT_SKIP_DIR
 #define BT_SKIP_DIR 1          // a wave of pass-through march steps skips the direction sampling
 #endif
@@ -1139,7 +1142,7 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
     // grid = tiles to render; with sample slicing a tile is S workgroups (see the mapping in the kernel); the streaming
     // queue launches P->stream_grid persistent workgroups instead
     const unsigned tpw = P->scratch || P->stream ? (unsigned)P->tiles_per_wg : 1u;
-    dim3 g(P->stream ? P->stream_grid : (tpw > 1 ? (grid + tpw - 1) / tpw : grid * (unsigned)P->slices)), b(256);
+    dim3 g(P->stream ? P->stream_grid : (tpw > 1 ? (grid + tpw - 1) / tpw : grid * (unsigned)P->slices)), b(P->scratch && !P->stream ? BT_WG_THREADS : 256);
     // 0 = a lane owns a pixel, 1 = block queue (parks in scratch), 2 = streaming queue; the lens builds have no streaming
     // instantiation (bt_api.cpp does not ask for one)
     const int qmode = P->stream ? 2 : (P->scratch != nullptr ? 1 : 0);
