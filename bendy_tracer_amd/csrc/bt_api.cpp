@@ -860,6 +860,20 @@ int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {
 #ifdef BT_STREAM_DEBUG                              // developer build of the whole library (FLAGS += -DBT_STREAM_DEBUG)
         fprintf(stderr, "[bt stream] lane-iterations %llu, waiting for a ring slot %llu, claim-lock spins %llu; watchdog: slot wait %#llx %#llx, claim %#llx\n", c[3], c[4], c[5], c[6], c[7], c[8]);
 #endif
+#ifdef BT_XCCSTAT
+        // developer build (-DBT_XCCSTAT): when each XCD's last wave ended, in microseconds after the first wave's start
+        {
+            const unsigned long long t0 = ~c[10];
+            fprintf(stderr, "[bt xcc] last wave of XCD 0..7 ended at (us):");
+#if BT_XCCSTAT == 2
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " [%llu workgroups]", c[2 + i]);
+            (void)t0;
+#else
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %.1f", c[2 + i] ? (double)(c[2 + i] - t0) / 100.0 : 0.0);
+#endif
+            fprintf(stderr, "\n");
+        }
+#endif
 #ifdef BT_LANESTAT
         // developer build (-DBT_LANESTAT): what the lanes of a wave do per iteration, see bt_kernels.hip
         if (c[2]) {

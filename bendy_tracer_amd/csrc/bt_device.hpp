@@ -730,7 +730,7 @@ BT_DEV float march_density_box(const BtLaunch &P, const SceneLds &S, int vol_ind
     // (min / max of the three magnitudes: two compares instead of nine; an exact 0 now also takes the exact path, and a
     // NaN component, which fminf / fmaxf skip, gives NaN on either path and is clamped to 0 by the sampler)
     const float ax = fabsf(rel.x), ay = fabsf(rel.y), az = fabsf(rel.z);
-    const bool in_range = (box.ok != 0.0f) & (fminf(fminf(ax, ay), az) >= 0x1p-60f) & (fmaxf(fmaxf(ax, ay), az) <= 0x1p60f);
+    const bool in_range = box.ok != 0.0f && fminf(fminf(ax, ay), az) >= 0x1p-60f && fmaxf(fmaxf(ax, ay), az) <= 0x1p60f;
     V3 coord;
     if (__ballot(!in_range) == 0ull) {
         coord = mk(div_refined(rel.x, size.x, box.rcp.x), div_refined(rel.y, size.y, box.rcp.y), div_refined(rel.z, size.z, box.rcp.z));

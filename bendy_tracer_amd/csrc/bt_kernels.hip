@@ -73,6 +73,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
 #define BT_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local")   // orders LDS accesses only (lgkmcnt)
 #define BT_RING_MAX 4               // most ring slots of the streaming queue (BtLaunch::ring_slots)
+#ifndef BT_NO_COUNTERS
+#define BT_NO_COUNTERS 0       // 1: timing experiment without the per-wave atomicAdd of the segment count
+#endif
 #ifndef BT_WG_THREADS
 #define BT_WG_THREADS 256      // lanes per workgroup of the block queue (A/B knob: 64 / 128 / 256)
 #endif
@@ -105,10 +108,14 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 template <int OUTPUT, bool LENS, int QMODE, bool RECTS, bool VOLS>
 __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : BT_WAVES_PER_SIMD)) BT_SGPR_ATTR void bt_render_kernel(BtLaunch P) {
     constexpr bool SLICED = QMODE != 0;    // samples come from a work queue and are parked for the ordered sum
+#ifdef BT_XCCSTAT
+    const unsigned long long xcc_t0 = wall_clock64();
+#endif
     constexpr bool STREAM = QMODE == 2;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_waves_done;      // block queue: waves of this workgroup that have parked all their samples
     __shared__ uint32_t s_next_item;       // the workgroup's work queue (next unclaimed (pixel, sample) pair)
+    __shared__ uint32_t s_segments;        // block queue: path segments traced by this workgroup
     __shared__ uint32_t s_summed;          // STREAM: units whose samples have been added to the frame (in order)
     __shared__ uint32_t s_ready;           // STREAM: bit r = the unit in ring slot r is complete and waits for its sum
     __shared__ uint32_t s_done[BT_RING_MAX]; // STREAM: finished items of the unit in ring slot r
@@ -119,6 +126,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     if (SLICED && threadIdx.x == 0) {
         s_waves_done = 0;
         s_next_item = 0;
+        s_segments = 0;
         s_summed = 0;
         s_ready = 0;
         for (int r = 0; r < BT_RING_MAX; ++r) s_done[r] = 0;
@@ -261,7 +269,12 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     bool held = false;
     float held_t = 0.0f;
     int held_info = 0, waited = 0;     // held_info = prim | inside << 29 | p_neg << 30
-    unsigned long long segments = 0, lens_steps = 0;
+    // path segments of this lane (bt_stats::segments).  The block queue counts in 32 bits (a lane sees at most
+    // scratch cap / 12 B / 256 items per launch) and adds up per workgroup in LDS: one device atomic per workgroup, issued
+    // by the wave that sums the block, instead of one 64-bit wave reduction + atomic per wave
+    constexpr bool WG_COUNT = SLICED && !STREAM && !LENS;
+    typename std::conditional<WG_COUNT, uint32_t, unsigned long long>::type segments = 0;
+    unsigned long long lens_steps = 0;
     LensState lens;                    // lens extension: the bent segment in progress (LENS builds only)
     bool bent = false;
     lens_begin(P, lens);
@@ -972,12 +985,22 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         // sample of the block's pixels, in sample order -- the additions the unsliced kernel performs in registers,
         // in the same order.  The parked values were written by waves of this workgroup (same CU, same L1/L2), so
         // workgroup-scope release / acquire is all the ordering that is needed.
+        if (WG_COUNT && P.counters && !BT_NO_COUNTERS) {
+            uint32_t sg = (uint32_t)segments;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sg += __shfl_xor(sg, off, 64);
+            if (lane == 0 && sg) atomicAdd(&s_segments, sg);          // LDS; ahead of this wave's s_waves_done below
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         uint32_t arrived = 0;
         if (lane == 0) arrived = atomicAdd(&s_waves_done, 1u);
         arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
         if (arrived == (blockDim.x >> 6) - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (WG_COUNT && P.counters && !BT_NO_COUNTERS && lane == 0) {
+                const uint32_t total = *(volatile uint32_t *)&s_segments;
+                if (total) atomicAdd(&P.counters[0], (unsigned long long)total);
+            }
             if (pxb >= 64) {
                 for (uint32_t q = lane; q < pxb; q += 64) {
                     const PixelRef r = locate(q);
@@ -1034,9 +1057,11 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             }
         }
     }
-    if (P.counters) {
-        unsigned long long s = wave_sum(segments);
-        if (lane == 0 && s) atomicAdd(&P.counters[0], s);
+    if (P.counters && !BT_NO_COUNTERS) {
+        if (!WG_COUNT) {
+            unsigned long long s = wave_sum((unsigned long long)segments);
+            if (lane == 0 && s) atomicAdd(&P.counters[0], s);
+        }
         if (LENS) {
             unsigned long long ls = wave_sum(lens_steps);
             if (lane == 0 && ls) atomicAdd(&P.counters[1], ls);
@@ -1045,6 +1070,19 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         {   // debug build: lane-iterations | lane-iterations spent waiting for a ring slot | wave spins on the claim lock
             const unsigned long long a = wave_sum(dbg_iters), b = wave_sum(dbg_blocked), c = wave_sum(dbg_spins);
             if (lane == 0) { atomicAdd(&P.counters[3], a); atomicAdd(&P.counters[4], b); atomicAdd(&P.counters[5], c); }
+        }
+#endif
+#ifdef BT_XCCSTAT
+        {   // developer build: when the last wave of every XCD ends (s_memrealtime, 100 MHz), and when the first wave starts
+            const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;   // HW_REG_XCC_ID[3:0]
+            const unsigned long long t = wall_clock64();
+#if BT_XCCSTAT == 2
+            if (threadIdx.x == 0) atomicAdd(&P.counters[2 + xcc], 1ull);      // workgroups per XCD instead
+            (void)t;
+            if (lane == 0) atomicMax(&P.counters[10], ~xcc_t0);
+#else
+            if (lane == 0) { atomicMax(&P.counters[2 + xcc], t); atomicMax(&P.counters[10], ~xcc_t0); }
+#endif
         }
 #endif
 #ifdef BT_LANESTAT
