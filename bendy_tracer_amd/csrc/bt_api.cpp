@@ -518,6 +518,9 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         }
     }
 
+#ifdef BT_LDS_PAD                                   // developer build: unused LDS per workgroup, to time lower occupancies
+    lds_bytes += BT_LDS_PAD;
+#endif
     if (lds_bytes > 158 * 1024)
         return set_error(BT_ERR_INVALID_ARG, "scene tables (" + std::to_string(s->flat.lds_bytes()) +
                                                  " bytes) exceed the 160 KB of LDS of a gfx950 CU");

@@ -73,6 +73,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
 #define BT_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local")   // orders LDS accesses only (lgkmcnt)
 #define BT_RING_MAX 4               // most ring slots of the streaming queue (BtLaunch::ring_slots)
+#ifndef BT_XCD_ROTATE
+#define BT_XCD_ROTATE 0        // A/B knob: rotate each group of eight blocks over the XCDs by (group * BT_XCD_ROTATE) mod 8
+#endif
 #ifndef BT_NO_COUNTERS
 #define BT_NO_COUNTERS 0       // 1: timing experiment without the per-wave atomicAdd of the segment count
 #endif
@@ -210,7 +213,14 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     const uint32_t NS = SLICED ? (uint32_t)P.slices : 1u;
     const uint32_t TPW = SLICED ? (uint32_t)P.tiles_per_wg : 1u;
     const uint32_t pxb = 256u * TPW / NS;              // pixels per block
+#if BT_XCD_ROTATE
+    // workgroups go to the 8 XCDs round robin: rotate the eight blocks of every group by the group's number, so that no
+    // XCD is tied to one column parity / quadrant of the tiles
+    const uint32_t bi = SLICED && !STREAM && blockIdx.x < (gridDim.x & ~7u)
+                            ? (blockIdx.x & ~7u) | ((blockIdx.x + (blockIdx.x >> 3) * BT_XCD_ROTATE) & 7u) : blockIdx.x;
+#else
     const uint32_t bi = blockIdx.x;                    // block index in launch order
+#endif
     const uint32_t lane = threadIdx.x & 63;
     // pixel q of this workgroup's block: frame coordinates, whether it exists, and where its running sum lives
     struct PixelRef { uint32_t px, py; bool in_frame; float *out; };
