@@ -423,20 +423,21 @@ struct SortedHit { float t; uint32_t prio; float psgn; };
 // into an SGPR pair per condition, s_and_b64 to combine them, v_cndmask per field) spends a dozen scalar instructions
 // per row, and the one scalar unit of a CU was the busiest part of the rect builds (profiles/r01g/pmcq_cornell_r01g.log:
 // 0.82 scalar instructions per CU-cycle).  ok_mask: lanes whose |q| passed the 1e-5 test (rect.rs:121-124);
-// a2 <= lim_a, b2 <= lim_b: Rect::contains_point (rect.rs:74-80); !(t < tmin): Clip (NaN passes, as in the C form, and
+// |a| <= lim_a, |b| <= lim_b: Rect::contains_point's `x * x <= w_sqr` (rect.rs:74-80) through the host's abs_limit(), the
+// multiplications saved; the hit's p = dp * (+-1) is stored as dp ^ sign mask (same sign, zeros and NaN included); !(t < tmin): Clip (NaN passes, as in the C form, and
 // then fails the containment tests); t against the running hit: sorted_accept()'s rule.
 #ifndef BT_ACCEPT_ASM
 #define BT_ACCEPT_ASM 1
 #endif
-BT_DEV void sorted_accept_rect(SortedHit &h, unsigned long long ok_mask, float t, float tmin, float a2, float lim_a, float b2,
-                               float lim_b, uint32_t prio, float psgn) {
+BT_DEV void sorted_accept_rect(SortedHit &h, unsigned long long ok_mask, float t, float tmin, float a, float lim_a, float b,
+                               float lim_b, uint32_t prio, float p, uint32_t sgn_mask) {
 #if BT_ACCEPT_ASM
     unsigned long long saved, tmp;
     asm volatile("s_mov_b64 %[sv], exec\n\t"
                  "s_and_b64 exec, exec, %[okm]\n\t"
                  "v_cmpx_ngt_f32 vcc, %[tmin], %[t]\n\t"
-                 "v_cmpx_ge_f32 vcc, %[lima], %[a2]\n\t"
-                 "v_cmpx_ge_f32 vcc, %[limb], %[b2]\n\t"
+                 "v_cmpx_ge_f32_e64 vcc, %[lima], |%[a]|\n\t"
+                 "v_cmpx_ge_f32_e64 vcc, %[limb], |%[b]|\n\t"
                  "v_cmpx_le_f32 vcc, %[t], %[ht]\n\t"
                  "v_cmp_eq_f32 vcc, %[t], %[ht]\n\t"
                  "v_cmp_le_u32 %[tmp], %[prio], %[hp]\n\t"
@@ -444,18 +445,18 @@ BT_DEV void sorted_accept_rect(SortedHit &h, unsigned long long ok_mask, float t
                  "s_andn2_b64 exec, exec, vcc\n\t"
                  "v_mov_b32 %[ht], %[t]\n\t"
                  "v_mov_b32 %[hp], %[prio]\n\t"
-                 "v_mov_b32 %[hs], %[ps]\n\t"
+                 "v_xor_b32 %[hs], %[sm], %[p]\n\t"
                  "s_mov_b64 exec, %[sv]"
                  : [ht] "+v"(h.t), [hp] "+v"(h.prio), [hs] "+v"(h.psgn), [sv] "=&s"(saved), [tmp] "=&s"(tmp)
-                 : [okm] "s"(ok_mask), [tmin] "s"(tmin), [t] "v"(t), [lima] "s"(lim_a), [a2] "v"(a2), [limb] "s"(lim_b),
-                   [b2] "v"(b2), [prio] "s"(prio), [ps] "v"(psgn)
+                 : [okm] "s"(ok_mask), [tmin] "s"(tmin), [t] "v"(t), [lima] "s"(lim_a), [a] "v"(a), [limb] "s"(lim_b),
+                   [b] "v"(b), [prio] "s"(prio), [p] "v"(p), [sm] "s"(sgn_mask)
                  : "vcc", "scc");
 #else
-    const bool ok = ((ok_mask >> (threadIdx.x & 63)) & 1) & !(t < tmin) & (a2 <= lim_a) & (b2 <= lim_b);
+    const bool ok = ((ok_mask >> (threadIdx.x & 63)) & 1) & !(t < tmin) & (fabsf(a) <= lim_a) & (fabsf(b) <= lim_b);
     const bool better = ok & ((t < h.t) | ((t == h.t) & (prio > h.prio)));
     h.t = better ? t : h.t;
     h.prio = better ? prio : h.prio;
-    h.psgn = better ? psgn : h.psgn;
+    h.psgn = better ? __uint_as_float(__float_as_uint(p) ^ sgn_mask) : h.psgn;
 #endif
 }
 BT_DEV void sorted_accept(SortedHit &h, bool ok, float t, uint32_t prio, float psgn) {
@@ -497,7 +498,7 @@ BT_DEV void aan_group(BtRectAANK *rows, int n, V3 o, V3 d, float tmin, SortedHit
         const float t = div_refined(dp, dq, r);     // == dp / dq (see above)
         const float la = (oa + da * t) + R.it_a;
         const float lb = (ob + db * t) + R.it_b;
-        sorted_accept_rect(h, dq_ok, t, tmin, la * la, R.lim_a, lb * lb, R.lim_b, R.prio, dp * R.sgn);
+        sorted_accept_rect(h, dq_ok, t, tmin, la, R.lim_a, lb, R.lim_b, R.prio, dp, R.sgn_mask);
     };
     int i = 0;
     for (; i + 1 < n; i += 2) {                     // two rows per trip: half the loop bookkeeping on the scalar unit
@@ -524,8 +525,7 @@ BT_DEV void la_rows(BtRectLAK *rows, int n, V3 o, V3 d, float tmin, SortedHit &h
         const V3 pos = o + d * t;
         const f2 ax = {R.a_x[0], R.a_x[1]}, ay = {R.a_y[0], R.a_y[1]}, az = {R.a_z[0], R.a_z[1]}, aw = {R.a_w[0], R.a_w[1]};
         const f2 l = ((ax * pos.x + ay * pos.y) + az * pos.z) + aw;       // (lu, lv) of rect_t()
-        const f2 l2 = l * l;
-        sorted_accept_rect(h, q_ok, t, tmin, l2.x, R.lim[0], l2.y, R.lim[1], R.prio, p);
+        sorted_accept_rect(h, q_ok, t, tmin, l.x, R.lim[0], l.y, R.lim[1], R.prio, p, 0u);
     }
 }
 BT_DEV HitRec intersect_sorted(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax) {

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 
 #include "../../include/bendy_hip.h"
 #include "bt_json.hpp"
@@ -442,12 +443,35 @@ FlatScene flatten_scene(const Scene &sc) {
         fs.root_color = add(shade_color, m.emitted);  // color_data.color += emitted (mod.rs:450)
     }
     // sorted view of the table for bt_device.hpp intersect_sorted()
+    // Rect::contains_point tests `x * x <= L` (rect.rs:74-80).  x -> fl(x * x) is monotone in |x| (rounding and underflow
+    // included), so the set of x that pass is |x| <= s for the largest float s with fl(s * s) <= L: found here by bisection
+    // over the bit patterns, with the same IEEE multiplication the kernel would perform.  The sorted rows carry s; the
+    // kernel compares |x| with it and saves the multiplication.  (L negative or NaN: nothing passes, s = -1.)
+    auto abs_limit = [](float L) -> float {
+        if (!(L >= 0.0f)) return -1.0f;
+        uint32_t lo = 0u, hi = 0x7f800000u;                 // fl(0 * 0) = 0 <= L holds
+        auto passes = [L](uint32_t bits) {
+            float x;
+            std::memcpy(&x, &bits, 4);
+            volatile float sq = x * x;
+            return sq <= L;
+        };
+        if (passes(hi)) return std::numeric_limits<float>::infinity();
+        while (hi - lo > 1u) {                              // passes(lo) && !passes(hi)
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            if (passes(mid)) lo = mid; else hi = mid;
+        }
+        float s;
+        std::memcpy(&s, &lo, 4);
+        return s;
+    };
     for (int axis = 0; axis < 3; ++axis)
         for (size_t i = 0; i < fs.prims.size(); ++i) {
             const BtPrim &p = fs.prims[i];
             if ((p.kind & BT_PRIM_SHAPE_MASK) != BT_PRIM_RECT_AAN || p.aa_w != axis) continue;
             BtRectAAN r{};
-            r.it_a = p.ax.y; r.it_b = p.ax.z; r.lim_a = p.ax_w; r.lim_b = p.ay.x; r.t_w = p.ax.x; r.sgn = p.ay.y;
+            r.it_a = p.ax.y; r.it_b = p.ax.z; r.lim_a = abs_limit(p.ax_w); r.lim_b = abs_limit(p.ay.x); r.t_w = p.ax.x;
+            r.sgn_mask = std::signbit(p.ay.y) ? 0x80000000u : 0u;
             r.prio = (p.kind & BT_PRIM_STRICT) ? 0xfffeu - (uint32_t)i : 0x10000u + (uint32_t)i;
             fs.aan_rows.push_back(r);
             fs.n_aan[axis] += 1;
@@ -471,7 +495,7 @@ FlatScene flatten_scene(const Scene &sc) {
                 r.prio = (p.kind & BT_PRIM_STRICT) ? 0xfffeu - (uint32_t)la[b] : 0x10000u + (uint32_t)la[b];
                 r.a_x[0] = p.ax.x; r.a_x[1] = p.ay.x; r.a_y[0] = p.ax.y; r.a_y[1] = p.ay.y; r.a_z[0] = p.ax.z; r.a_z[1] = p.ay.z;
                 r.a_w[0] = p.ax_w; r.a_w[1] = p.ay_w;
-                r.lim[0] = p.w_sqr; r.lim[1] = p.h_sqr;
+                r.lim[0] = abs_limit(p.w_sqr); r.lim[1] = abs_limit(p.h_sqr);
                 fs.la_rows.push_back(r);
                 done[b] = true;
             }

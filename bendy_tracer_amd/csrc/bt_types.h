@@ -71,9 +71,9 @@ static_assert(sizeof(BtSpherePair) == 48, "BtSpherePair must be 48 bytes");
 // latter (0xffff = no hit yet); the hit with the smallest t wins, among equal t the largest prio.
 struct BtRectAAN {
     float it_a, it_b;       // it[a], it[b] of the inverse transform (a < b the in-plane axes): an aligned SGPR pair
-    float lim_a, lim_b;     // squared half extents along a, b
+    float lim_a, lim_b;     // largest |x| whose square passes `x * x <= w_sqr` / `<= h_sqr` (bt_scene.cpp abs_limit)
     float t_w;              // t[w]
-    float sgn;              // c[w] = +-1
+    uint32_t sgn_mask;      // sign bit of c[w] = +-1: p = (t[w] - o[w]) * c[w] has the sign of (t[w] - o[w]) ^ sgn_mask
     uint32_t prio;
     uint32_t pad;
 };
@@ -87,7 +87,7 @@ struct BtRectLA {
     BtV3 t;                 // transform.translation
     uint32_t prio;
     float a_x[2], a_y[2], a_z[2], a_w[2];   // (ax, ay) component pairs; a_w = (ax_w, ay_w)
-    float lim[2];           // (w_sqr, h_sqr)
+    float lim[2];           // abs_limit(w_sqr), abs_limit(h_sqr)
     uint32_t pad[2];
 };
 static_assert(sizeof(BtRectLA) == 80, "BtRectLA must be 80 bytes");
