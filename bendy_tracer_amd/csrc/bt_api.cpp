@@ -394,6 +394,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             safe = safe && v.width >= 1 && v.height >= 1 && v.depth >= 1 && v.size.x >= 0.0f && v.size.y >= 0.0f && v.size.z >= 0.0f &&
                    std::ceil(v.size.x) <= (float)(v.width - 1) && std::ceil(v.size.y) <= (float)(v.height - 1) &&
                    std::ceil(v.size.z) <= (float)(v.depth - 1);
+        safe = safe && s->flat.density.size() < (1u << 24);      // density_sample_safe() indexes with 24-bit multiply-adds
         P.vols_safe = safe ? 1 : 0;
         P.vbox_lds_bytes = real_volumes ? (uint32_t)(sizeof(BtVolBox) * s->flat.prims.size()) : 0u;
         if (lds_bytes + P.vbox_lds_bytes > 32 * 1024) P.vbox_lds_bytes = 0;          // big scenes keep the per-step arithmetic

@@ -705,16 +705,24 @@ BT_DEV BlockPixel block_pixel(uint32_t sub, uint32_t q, uint32_t pxb) {
 // DensityMap::sample for maps whose bounds tests cannot fire (BtLaunch::vols_safe): density_sample() without the clamp of
 // negative indices and the width / height / depth tests of density_at() -- cx = clamp(coord, 0, 1) * size lies in
 // [0, size] (NaN clamps to 0), so floor and ceil lie in [0, dim - 1].  Same fetches, same lerps, same bits.
-BT_DEV float density_sample_safe(const BtVolume &vol, const float *density, V3 coord) {
+// Ptr: the map in LDS (address space 3: ds_read with 32-bit addressing) or wherever `const float *` points (a map beyond the
+// LDS budget stays in global memory; through the generic pointer every fetch is a flat load with a 64-bit address).
+// Indices are non-negative and the map has fewer than 2^24 cells (vols_safe), so the row arithmetic runs in 24-bit
+// multiply-adds (full rate) instead of v_mul_lo_u32.
+template <class Ptr>
+BT_DEV float density_sample_safe(const BtVolume &vol, Ptr density, V3 coord) {
     const float cx = fminf(fmaxf(coord.x, 0.0f), 1.0f) * vol.size.x;
     const float cy = fminf(fmaxf(coord.y, 0.0f), 1.0f) * vol.size.y;
     const float cz = fminf(fmaxf(coord.z, 0.0f), 1.0f) * vol.size.z;
     const float fx = floorf(cx), fy = floorf(cy), fz = floorf(cz);
     const float tx = cx - truncf(cx), ty = cy - truncf(cy), tz = cz - truncf(cz);
-    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz, x1 = (int)ceilf(cx), y1 = (int)ceilf(cy), z1 = (int)ceilf(cz);
-    const float *d = density + vol.offset;
-    const int r00 = (z0 * vol.height + y0) * vol.width, r01 = (z0 * vol.height + y1) * vol.width;
-    const int r10 = (z1 * vol.height + y0) * vol.width, r11 = (z1 * vol.height + y1) * vol.width;
+    const uint32_t x0 = (uint32_t)fx, y0 = (uint32_t)fy, z0 = (uint32_t)fz;
+    const uint32_t x1 = (uint32_t)ceilf(cx), y1 = (uint32_t)ceilf(cy), z1 = (uint32_t)ceilf(cz);
+    const uint32_t W = (uint32_t)vol.width, H = (uint32_t)vol.height;
+    Ptr d = density + vol.offset;
+    const uint32_t zh0 = __umul24(z0, H), zh1 = __umul24(z1, H);
+    const uint32_t r00 = __umul24(zh0 + y0, W), r01 = __umul24(zh0 + y1, W);
+    const uint32_t r10 = __umul24(zh1 + y0, W), r11 = __umul24(zh1 + y1, W);
     const float a = lerpf(d[r00 + x0], d[r00 + x1], tx), b = lerpf(d[r01 + x0], d[r01 + x1], tx);
     const float z_lo = lerpf(a, b, ty);
     const float c = lerpf(d[r10 + x0], d[r10 + x1], tx), e = lerpf(d[r11 + x0], d[r11 + x1], tx);
@@ -737,7 +745,11 @@ BT_DEV float march_density_box(const BtLaunch &P, const SceneLds &S, int vol_ind
     } else {
         coord = mk(rel.x / size.x, rel.y / size.y, rel.z / size.z);
     }
-    return P.volume_step * (P.vols_safe ? density_sample_safe(vol, S.density, coord) : density_sample(vol, S.density, coord));
+    typedef const __attribute__((address_space(3))) float *LdsF;
+    float dens;
+    if (P.vols_safe && P.n_density <= BT_DENSITY_LDS_MAX) dens = density_sample_safe(vol, (LdsF)S.density, coord);   // the kernel's dens_lds
+    else dens = density_sample(vol, S.density, coord);       // a map in global memory, or one whose bounds tests can fire
+    return P.volume_step * dens;
 }
 
 // The scatter probability of one march step, Volume::shade's `volume_step * density.sample(coord)` (volume.rs:26-35)

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 5) void bt_render_sorted_kernel(BtLaunch P) {
         for (int i = threadIdx.x; i < P.n_volumes; i += blockDim.x) vols[i] = P.volumes[i];
         for (int i = threadIdx.x; i < P.n_lights; i += blockDim.x) lights[i] = P.lights[i];
         for (int i = threadIdx.x; i < P.n_light_faces; i += blockDim.x) faces[i] = P.light_faces[i];
-        const bool dens_lds = P.n_density > 0 && P.n_density <= 8192;
+        const bool dens_lds = P.n_density > 0 && P.n_density <= BT_DENSITY_LDS_MAX;
         if (dens_lds)
             for (int i = threadIdx.x; i < P.n_density; i += blockDim.x) dens[i] = P.density[i];
         S.lite = lite; S.materials = mats; S.volumes = vols; S.lights = lights; S.faces = faces;

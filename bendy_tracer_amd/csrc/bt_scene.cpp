@@ -265,7 +265,7 @@ size_t FlatScene::lds_bytes() const {
     size_t n = sizeof(BtPrimLite) * prims.size() + sizeof(BtMaterial) * materials.size() +
                sizeof(BtVolume) * volumes.size() + sizeof(BtLight) * lights.size() +
                sizeof(BtLightFace) * light_faces.size();
-    if (!density.empty() && density.size() <= 8192) n += sizeof(float) * density.size();
+    if (!density.empty() && density.size() <= BT_DENSITY_LDS_MAX) n += sizeof(float) * density.size();
     return (n + 15) & ~(size_t)15;
 }
 

@@ -9,6 +9,7 @@
 #else
 #define BT_N_COUNTERS 2
 #endif
+#define BT_DENSITY_LDS_MAX 8192   // density maps up to this many cells are staged in LDS (32 KB)
 #define BT_BLOCK_COUNTER_SLOT 15 // d_counters[15] is the streaming queue's block counter (the array holds 16 words)
 
 struct BtV3 { float x, y, z; };
