@@ -73,6 +73,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
 #define BT_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local")   // orders LDS accesses only (lgkmcnt)
 #define BT_RING_MAX 4               // most ring slots of the streaming queue (BtLaunch::ring_slots)
+#ifndef BT_VOTE_SOFT_K
+#define BT_VOTE_SOFT_K 0       // A/B knob, see the phase vote
+#endif
 #ifndef BT_XCD_ROTATE
 #define BT_XCD_ROTATE 0        // A/B knob: rotate each group of eight blocks over the XCDs by (group * BT_XCD_ROTATE) mod 8
 #endif
@@ -638,7 +641,18 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             const bool run_gen = (n_gen >= n_sc && n_gen >= n_vol) || (starving & m_gen) != 0;
             const bool run_sc = (n_sc > n_gen && n_sc >= n_vol) || (starving & m_sc) != 0;
             const bool run_vol = (n_vol > n_gen && n_vol > n_sc) || (starving & m_vol) != 0;
-            const bool served = want_gen ? run_gen : (want_vol ? run_vol : run_sc);
+            bool served = want_gen ? run_gen : (want_vol ? run_vol : run_sc);
+#if BT_VOTE_SOFT_K > 0
+            // soft batching (A/B knob): in builds with volumes a surface event (Diffuse / Metallic / Glass) that shares its
+            // wave with march steps waits until BT_VOTE_SOFT_K surface lanes have gathered (or one of them has waited
+            // long enough): the march steps never wait for it
+            if (VOLS && !BT_VOTE3) {
+                const bool surf = want_sc && ev != EV_VOLUME;
+                const unsigned long long m_surf = __ballot(surf);
+                const bool run_surf = __popcll(m_surf) >= BT_VOTE_SOFT_K || (starving & m_surf) != 0 || m_surf == m_sc;
+                if (surf && !run_surf) served = false;
+            }
+#endif
             BT_LS(7, __ballot(!served));
             if (!served) {
                 waited += 1;
