@@ -28,6 +28,9 @@ bytes (`traffic`) and every counter MEASURED IN THIS RUN by rocprofv3 --pmc pass
 committed summary profiles/pmc_live.json is quoted and flagged `stale` when its source hash differs from this tree.
 `cpu_baseline` (N = 1): the CPU oracle -- a C port of the reference algorithm, NOT the Rust binary -- timed on the host
 cores on a bounded sample of the same workload.
+
+`other_configs` (N = 1 only; not part of `value`): a few renders each of BASELINE.json's other configurations on this GPU
+-- C2, C4, C5 rendered whole on one GPU, the 1080p Cornell box -- with wall and kernel time per `Tracer::render`.
 """
 import argparse
 import json
@@ -167,6 +170,36 @@ def lens_extension_rate(b, torch, scene_name, w, h, spp=64, steps=2):
             "note": "extension, not in the reference; fixed-step RK4 on the Schwarzschild null geodesic"}
 
 
+def other_configs(b, torch, steps=3):
+    """The other BASELINE.json configurations on this GPU, a few renders each (they are parity-test cases, not the
+    headline; `value` stays C3): per `Tracer::render` the wall time around the call (synchronised) and the kernel time by
+    the library's HIP events.  C5 is configs[4]'s frame and depth rendered whole on ONE GPU (its 8-GPU form needs the
+    driver's node)."""
+    out = {}
+    for name in ("C2", "C4", "C5", "cornell1080"):
+        scene_name, w, h, spp = WORKLOADS[name]
+        sc = b.Scene.load(os.path.join(ROOT, "scenes", f"{scene_name}.json.gz"))
+        cam = sc.find_by_tag("camera")
+        sc.set_camera_aspect(cam, w / h)
+        buf = b.Buffer.new(w, h)
+        tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
+        wall, kern = [], []
+        for i in range(steps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr.render(sc, cam, b.RenderConfig.with_samples(spp), buf, seed=SEED, sample_base=i * spp)
+            torch.cuda.synchronize()
+            wall.append((time.perf_counter() - t0) * 1e3)
+            kern.append(sc.last_stats().kernel_ms)
+        st = sc.last_stats()
+        ms = statistics.mean(wall[1:])
+        out[name] = {"workload": f"{scene_name}.json.gz {w}x{h}x{spp}spp", "value": round(w * h * spp / ms / 1e3, 1),
+                     "unit": "Msamples/s", "ms_per_render": round(ms, 4), "kernel_ms": round(statistics.mean(kern[1:]), 4),
+                     "segments_per_sample": round(st.segments / st.samples, 4), "launches": st.launches}
+        del buf, sc
+    return out
+
+
 class ShardExchange:
     """Rank-local shard of running sums + the frame exchange of the N > 1 path."""
 
@@ -237,6 +270,7 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short timing of C2 / C4 / C5 / Cornell at N = 1")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (quote the committed summary)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "rccl-abi", "gloo"],
@@ -428,6 +462,8 @@ def main():
             out["final_gather_only"] = final_only
         if world == 1 and args.workload == "C3" and not args.force_dist:
             out["lens_extension"] = lens_extension_rate(b, torch, scene_name, w, h)
+            if not args.no_other_configs:
+                out["other_configs"] = other_configs(b, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_name, w, h, args.cpu_budget)
             out["parity"] = parity_figure(b, torch, scene_name)

@@ -11,7 +11,7 @@ TAG=${1:-r02}; COMMIT=${2:-unknown}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/bench_under_trace.log 2>$OUT/trace.err || tail -3 $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-other-configs > $OUT/bench_under_trace.log 2>$OUT/trace.err || tail -3 $OUT/trace.err
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 for wl in C3 C2 C4 cornell1080 cloud1080; do
   python3 tools/pmc_collect.py --workload $wl --passes fetch,write,sq,classes,waits --commit $COMMIT --out $OUT/pmc_$wl.json > /dev/null 2>$OUT/pmc_$wl.err || { echo "pmc $wl failed"; tail -3 $OUT/pmc_$wl.err; }
