@@ -320,6 +320,7 @@ int fill_launch(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt
     P.width = width;
     P.height = height;
     P.tiles_x = (width + BT_TILE_DIM - 1) / BT_TILE_DIM;
+    P.tiles_x_magic = P.tiles_x == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / P.tiles_x);   // kernels: tile / tiles_x by umulhi + one fix-up
     P.tiles_y = (height + BT_TILE_DIM - 1) / BT_TILE_DIM;
     P.rank = 0;
     P.world = 1;
@@ -423,7 +424,8 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     // 0 = a lane owns a pixel, 1 = block queue (the default whenever a pixel gets more than one ray), 2 = streaming queue
     // (opt-in through bt_tuning.queue -- no multi-GB scratch, no drain at the end of a block, 65 x less HBM
     // traffic with its ring in LDS, but 25 % slower on C3 as measured in round 2, profiles/r02e)
-    int qmode = T_all >= 2 ? 1 : 0;
+    int qmode = 1;      // also for one ray per pixel: a lane that takes the next pixel when its path ends beats a lane that
+                        // owns one pixel by 1.4 ... 2.9 x (profiles/r02z/time_t1.log: scene.json 1080p 0.44 -> 0.15 ms per call)
     if (tune.queue >= 0) qmode = tune.queue == 2 && P.lens_on ? 1 : tune.queue;
     if (qmode == 2 && T_all * (uint64_t)BT_TILE_DIM * BT_TILE_DIM * grid >= (1ull << 40)) qmode = 1;   // item counters are 32 bit per workgroup
     uint64_t parked_bytes = 0;
@@ -455,7 +457,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         if (last_T * pxb < 64 && n_chunks > 1) {
             qmode = 1;                                                           // odd sample count that does not cut evenly: block queue
         } else if (T * pxb < 64) {
-            qmode = T_all >= 2 ? 1 : 0;
+            qmode = 1;
         } else {
             P.stream = 1;
             P.slices = (int32_t)S;
@@ -467,7 +469,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             P.unit_cap = pxb * chunk_T;
             P.stream_grid = std::min<uint32_t>(P.n_blocks, G_full);
             P.block_counter = (uint32_t *)(s->d_counters + BT_BLOCK_COUNTER_SLOT);
-            P.tiles_x_magic = P.tiles_x == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / P.tiles_x);
+
             lds_bytes += 3 * 64 * 4 + (ring_lds ? (size_t)R * P.unit_cap * 12 : 0);
             const uint64_t need = ring_lds ? 0 : (uint64_t)P.stream_grid * R * P.unit_cap * 3 * sizeof(float);
             if (!ensure_scratch(need)) return set_error(BT_ERR_DEVICE, "no device memory for the parked samples");
@@ -487,10 +489,16 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         auto pick = [&](uint64_t T) -> uint32_t {
             if (tune.slices) return tune.slices;
             uint32_t S = 1;
-            const uint64_t per_lane = P.lens_on ? 4 : 16;
-            while (S < 32 && T / (2 * S) >= per_lane) S *= 2;
+            if (P.lens_on) {
+                while (S < 32 && T / (2 * S) >= 4) S *= 2;       // lens paths differ far more in length: ~4 samples per lane
+            } else {
+                // measured on 1080p frames, T = 1 ... 128 rays per pixel per launch (profiles/r02z/time_shallow_before.log): blocks
+                // of whole 8x8 quadrants (S <= 4) with >= 4 samples per lane on sphere scenes, >= 8 ... 16 with rects / volumes
+                if (P.any_rects || P.any_volumes) S = T >= 64 ? 4 : (T >= 16 ? 2 : 1);
+                else S = T >= 16 ? 4 : (T >= 8 ? 2 : 1);
+            }
             const uint64_t waves = (uint64_t)grid * 4;
-            while (S < 16 && waves * S < 4 * wave_slots && T / (2 * S) >= 4) S *= 2;
+            while (S < 32 && waves * S < 4 * wave_slots && T / (2 * S) >= 4) S *= 2;
             return S;
         };
         bool queue = qmode != 0;
@@ -502,15 +510,11 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         if (queue) {
             P.slices = (int32_t)pick((uint64_t)chunk * nn);
             P.scratch = s->d_scratch;
-            // shallow launches (the interactive pattern, 1 sample x Subpixel(2) per call): whole tiles, two or four per
-            // workgroup, so that a lane still gets ~8 items -- while the launch keeps >= 2 rounds of workgroups.  Pays
-            // where samples are cheap (scene.json 0.58 -> 0.48 ms per 1080p call); with rects or volumes four items
-            // are work enough and fewer workgroups only lengthen the tail (profiles/r01g/time_progressive_tpw.log).
-            const uint64_t T = (uint64_t)chunk * nn;
-            uint32_t tpw = 1;
-            while (P.slices == 1 && !P.any_rects && !P.any_volumes && tpw < 4 && 256ull * (2 * tpw) * T <= 4096 &&
-                   (uint64_t)grid / (2 * tpw) >= 2 * (uint64_t)s->n_cu * 7)   /* >= two rounds of 7 workgroups per CU */
-                tpw *= 2;
+            // whole tiles, two or four per workgroup (bt_tuning.tiles_per_wg): round 1 chose two for the interactive pattern
+            // on sphere scenes; with round 2's cheaper samples one tile per workgroup is faster at every depth
+            // (profiles/r02z/time_shallow_before.log: scene.json T = 4: 0.35 vs 0.43 ms), so the automatic choice is 1 -- except for one
+            // ray per pixel, where two tiles (two items per lane) win on all three scene classes (time_t1.log)
+            uint32_t tpw = (uint64_t)chunk * nn == 1 && P.slices == 1 ? 2 : 1;      // one ray per pixel: 512 items per workgroup
             if (tune.tiles_per_wg && P.slices == 1) tpw = tune.tiles_per_wg;
             P.tiles_per_wg = (int32_t)tpw;
             parked_bytes = px_launch * T_all * 3 * sizeof(float);

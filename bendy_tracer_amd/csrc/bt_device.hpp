@@ -695,9 +695,11 @@ BT_DEV BlockPixel block_pixel(uint32_t sub, uint32_t q, uint32_t pxb) {
         r.x = ((quad & 1) << 3) | (q & 7);
         r.y = ((quad >> 1) << 3) | ((q & 63) >> 3);
     } else {
-        const uint32_t bw = pxb >= 32 ? 8u : 4u, bh = pxb / bw, nbx = 16u / bw;      // 8x4, 4x4, 4x2
-        r.x = (sub % nbx) * bw + q % bw;
-        r.y = (sub / nbx) * bh + q / bw;
+        // 8x4, 4x4, 4x2: every size is a power of two -- shifts and masks (a `%` by a value the compiler cannot see is a
+        // twenty-instruction division, and this runs once per work item)
+        const uint32_t lbw = pxb >= 32 ? 3u : 2u, lbh = (uint32_t)__builtin_ctz(pxb) - lbw, lnbx = 4u - lbw;
+        r.x = ((sub & ((1u << lnbx) - 1u)) << lbw) + (q & ((1u << lbw) - 1u));
+        r.y = ((sub >> lnbx) << lbh) + (q >> lbw);
     }
     return r;
 }

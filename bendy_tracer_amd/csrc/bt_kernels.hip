@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     // still gets ~8 items and the drain at the end of a workgroup stays short (BtLaunch::tiles_per_wg).
     const uint32_t NS = SLICED ? (uint32_t)P.slices : 1u;
     const uint32_t TPW = SLICED ? (uint32_t)P.tiles_per_wg : 1u;
-    const uint32_t pxb = 256u * TPW / NS;              // pixels per block
+    const uint32_t LOG_NS = (uint32_t)__builtin_ctz(NS);
+    const uint32_t pxb = (256u * TPW) >> LOG_NS;       // pixels per block
 #if BT_XCD_ROTATE
     // workgroups go to the 8 XCDs round robin: rotate the eight blocks of every group by the group's number, so that no
     // XCD is tied to one column parity / quadrant of the tiles
@@ -228,10 +229,11 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     // pixel q of this workgroup's block: frame coordinates, whether it exists, and where its running sum lives
     struct PixelRef { uint32_t px, py; bool in_frame; float *out; };
     auto locate = [&](uint32_t q) -> PixelRef {
-        const uint32_t slot = TPW > 1 ? bi * TPW + (q >> 8) : bi / NS;              // tile slot in launch order
-        const BlockPixel b = TPW > 1 ? block_pixel(0, q & 255u, 256u) : block_pixel(bi % NS, q, pxb);
+        const uint32_t slot = TPW > 1 ? bi * TPW + (q >> 8) : bi >> LOG_NS;         // tile slot in launch order (NS = 2^LOG_NS)
+        const BlockPixel b = TPW > 1 ? block_pixel(0, q & 255u, 256u) : block_pixel(bi & (NS - 1u), q, pxb);
         const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
-        const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+        uint32_t ty = __umulhi(tile, P.tiles_x_magic), tx = tile - ty * P.tiles_x;      // tile / tiles_x, exact after the fix-up
+        if (tx >= P.tiles_x) { ty += 1u; tx -= P.tiles_x; }
         PixelRef r;
         r.px = tx * BT_TILE_DIM + b.x;
         r.py = ty * BT_TILE_DIM + b.y;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     // wave that finishes a unit's last item adds the unit to the running sums in sample order -- units strictly in
     // sequence, so a pixel's chunks add up in order -- and only then may items of the unit ring_slots further on start.
     const uint32_t R_MASK = STREAM ? (uint32_t)P.ring_slots - 1u : 0u;           // ring_slots is 2 or 4
-    const uint32_t LOG_PXB = STREAM ? (uint32_t)__builtin_ctz(pxb) : 0u, LOG_NS = STREAM ? (uint32_t)__builtin_ctz(NS) : 0u;
+    const uint32_t LOG_PXB = STREAM ? (uint32_t)__builtin_ctz(pxb) : 0u;
     const uint32_t n_chunks = STREAM ? (uint32_t)P.n_chunks : 1u, chunk_T = STREAM ? (uint32_t)P.chunk_T : T;
     const uint32_t last_T = T - chunk_T * (n_chunks - 1u);                      // samples of a block's last chunk
 #ifdef BT_STREAM_DEBUG
@@ -1051,7 +1053,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             } else {
                 // 32, 16 or 8 pixels (deep launches, T in the hundreds): J = 64 / pxb lanes per pixel fetch interleaved
                 // samples (8 J in flight per pixel), lane (q, 0) adds them in sample order out of the others' registers
-                const uint32_t J = 64u / pxb, q = lane % pxb, jl = lane / pxb;
+                const uint32_t J = 64u >> LOG_PXB_ALL, q = lane & (pxb - 1u), jl = lane >> LOG_PXB_ALL;
                 const PixelRef r = locate(q);
                 const bool owner = jl == 0 && r.in_frame;
                 float *o = r.out;
