@@ -492,10 +492,13 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             if (P.lens_on) {
                 while (S < 32 && T / (2 * S) >= 4) S *= 2;       // lens paths differ far more in length: ~4 samples per lane
             } else {
-                // measured on 1080p frames, T = 1 ... 128 rays per pixel per launch (profiles/r02z/time_shallow_before.log): blocks
-                // of whole 8x8 quadrants (S <= 4) with >= 4 samples per lane on sphere scenes, >= 8 ... 16 with rects / volumes
-                if (P.any_rects || P.any_volumes) S = T >= 64 ? 4 : (T >= 16 ? 2 : 1);
-                else S = T >= 16 ? 4 : (T >= 8 ? 2 : 1);
+                // Measured on 1080p frames, T = 1 ... 128 rays per pixel per launch, and on the shards of 2 / 4 / 8 ranks with
+                // 128 / 256 / 512 rays (profiles/r02z/time_shallow_before.log, time_shard.log): what a launch wants is
+                // ~21 rounds of workgroups over the GPU (tiles x S ~ 32 000 on 256 CUs: S = 4 for a full 1080p frame, 8 / 16 / 32
+                // for the shards) as long as a lane still gets >= 4 samples (>= 8 with rects or volumes, whose samples cost more)
+                const uint64_t target = 21ull * (uint64_t)s->n_cu * 6;
+                const uint64_t min_items = P.any_rects || P.any_volumes ? 8 : 4;
+                while (S < 32 && (uint64_t)grid * (2 * S) * 4 <= 5 * target && T / (2 * S) >= min_items) S *= 2;
             }
             const uint64_t waves = (uint64_t)grid * 4;
             while (S < 32 && waves * S < 4 * wave_slots && T / (2 * S) >= 4) S *= 2;
