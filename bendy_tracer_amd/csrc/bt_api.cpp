@@ -488,20 +488,21 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         const uint64_t cap = tune.scratch_cap_bytes ? tune.scratch_cap_bytes : kDefaultScratchCap;
         auto pick = [&](uint64_t T) -> uint32_t {
             if (tune.slices) return tune.slices;
+            if (tune.tiles_per_wg > 1) return 1;                  // several whole tiles per workgroup: no cut inside a tile
             uint32_t S = 1;
             if (P.lens_on) {
                 while (S < 32 && T / (2 * S) >= 4) S *= 2;       // lens paths differ far more in length: ~4 samples per lane
             } else {
-                // Measured on 1080p frames, T = 1 ... 128 rays per pixel per launch, and on the shards of 2 / 4 / 8 ranks with
-                // 128 / 256 / 512 rays (profiles/r02z/time_shallow_before.log, time_shard.log): what a launch wants is
-                // ~21 rounds of workgroups over the GPU (tiles x S ~ 32 000 on 256 CUs: S = 4 for a full 1080p frame, 8 / 16 / 32
-                // for the shards) as long as a lane still gets >= 4 samples (>= 8 with rects or volumes, whose samples cost more)
+                // Measured on 1080p and 512 x 512 frames, T = 1 ... 128 rays per pixel per launch, and on the shards of 2 / 4 / 8
+                // ranks with 128 / 256 / 512 rays (profiles/r02z/time_shallow_before.log, time_shallow_512_before.log, time_shard.log).
+                // A launch wants ~21 rounds of workgroups over the GPU (tiles x S ~ 32 000 on 256 CUs: S = 4 for a full 1080p
+                // frame, 8 / 16 / 32 for the shards) with >= 8 samples per lane; below half of that, 4 samples per lane are
+                // enough; and a frame that cannot even fill the wave slots twice is cut down to one sample per lane.
                 const uint64_t target = 21ull * (uint64_t)s->n_cu * 6;
-                const uint64_t min_items = P.any_rects || P.any_volumes ? 8 : 4;
-                while (S < 32 && (uint64_t)grid * (2 * S) * 4 <= 5 * target && T / (2 * S) >= min_items) S *= 2;
+                while (S < 32 && (uint64_t)grid * (2 * S) * 4 <= 5 * target && T / (2 * S) >= 8) S *= 2;
+                while (S < 32 && (uint64_t)grid * S * 2 < target && T / (2 * S) >= 4) S *= 2;
+                while (S < 32 && (uint64_t)grid * 4 * S < 2 * wave_slots && T / (2 * S) >= 1) S *= 2;
             }
-            const uint64_t waves = (uint64_t)grid * 4;
-            while (S < 32 && waves * S < 4 * wave_slots && T / (2 * S) >= 4) S *= 2;
             return S;
         };
         bool queue = qmode != 0;
@@ -517,7 +518,8 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             // on sphere scenes; with round 2's cheaper samples one tile per workgroup is faster at every depth
             // (profiles/r02z/time_shallow_before.log: scene.json T = 4: 0.35 vs 0.43 ms), so the automatic choice is 1 -- except for one
             // ray per pixel, where two tiles (two items per lane) win on all three scene classes (time_t1.log)
-            uint32_t tpw = (uint64_t)chunk * nn == 1 && P.slices == 1 ? 2 : 1;      // one ray per pixel: 512 items per workgroup
+            // one ray per pixel: 512 items per workgroup where the frame has tiles enough for four rounds of those
+            uint32_t tpw = (uint64_t)chunk * nn == 1 && P.slices == 1 && (uint64_t)grid >= 4ull * s->n_cu * 6 ? 2 : 1;
             if (tune.tiles_per_wg && P.slices == 1) tpw = tune.tiles_per_wg;
             P.tiles_per_wg = (int32_t)tpw;
             parked_bytes = px_launch * T_all * 3 * sizeof(float);

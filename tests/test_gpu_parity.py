@@ -270,7 +270,7 @@ def test_several_tiles_per_workgroup(bendy, oracle, tiles, world):
     import torch
     w, h = 150, 75                                   # 10 x 5 tiles, ragged right / bottom edge
     it, _ = oracle_render(oracle, "cornell2", w, h, 1, n=2)
-    sc, cam = gpu_scene(bendy, "cornell2", w, h, tuning={"tiles_per_wg": tiles})
+    sc, cam = gpu_scene(bendy, "cornell2", w, h, tuning={"tiles_per_wg": tiles, "slices": 1})    # whole tiles: S = 1
     tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
     rc = bendy.RenderConfig.with_samples_subsample(1, bendy.Subsample(2))
     if world == 1:

@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
 import bendy_tracer_amd as b
-w, h = 1920, 1080
+w, h = (int(x) for x in os.environ.get('BT_FRAME', '1920x1080').split('x'))
 names = os.environ.get('BT_ONLY', 'scene,cornell2,volume').split(',')
 for name in names:
     sc = b.Scene.load(f'scenes/{name}.json.gz'); cam = sc.find_by_tag('camera'); sc.set_camera_aspect(cam, w / h)
