@@ -184,7 +184,8 @@ def other_configs(b, torch, steps=3):
         buf = b.Buffer.new(w, h)
         tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
         wall, kern = [], []
-        for i in range(steps + 1):
+        n = steps * 8 if w * h * spp < (1 << 24) else steps          # small configurations: more renders, first one untimed
+        for i in range(n + 1):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             tr.render(sc, cam, b.RenderConfig.with_samples(spp), buf, seed=SEED, sample_base=i * spp)
