@@ -198,6 +198,33 @@ def other_configs(b, torch, steps=3):
                      "unit": "Msamples/s", "ms_per_render": round(ms, 4), "kernel_ms": round(statistics.mean(kern[1:]), 4),
                      "segments_per_sample": round(st.segments / st.samples, 4), "launches": st.launches}
         del buf, sc
+    # the reference's interactive loop with its CLI defaults (main.rs:52-65, 245-254): a 768 x 512 window, one
+    # Tracer::render per displayed frame with samples = 1 and Subsample::Subpixel(2), scene.json
+    w, h = 768, 512
+    sc = b.Scene.load(os.path.join(ROOT, "scenes", "scene.json.gz"))
+    cam = sc.find_by_tag("camera")
+    sc.set_camera_aspect(cam, w / h)
+    buf = b.Buffer.new(w, h)
+    tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
+    rc = b.RenderConfig.with_samples_subsample(1, b.Subsample(2))
+    for _ in range(4):
+        tr.render(sc, cam, rc, buf, seed=SEED)
+    torch.cuda.synchronize()
+    lat = []
+    for _ in range(32):                              # the loop reads a preview back after every call: synchronised latency
+        t0 = time.perf_counter()
+        tr.render(sc, cam, rc, buf, seed=SEED)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    t0 = time.perf_counter()
+    for _ in range(64):
+        tr.render(sc, cam, rc, buf, seed=SEED)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / 64
+    out["interactive_default"] = {"workload": "scene.json.gz 768x512, 1 sample x Subpixel(2) per call (the reference CLI's defaults)",
+                                  "value": round(w * h * 4 / ms / 1e3, 1), "unit": "Msamples/s", "ms_per_call_pipelined": round(ms, 4),
+                                  "ms_per_call_synchronised": round(statistics.median(lat), 4),
+                                  "kernel_ms": round(sc.last_stats().kernel_ms, 4), "slices": sc.last_stats().slices}
     return out
 
 
