@@ -93,9 +93,9 @@ typedef struct {
  * tools/ set these to pin a shape; none of them can change a pixel (tests/test_gpu_parity.py renders every setting). */
 typedef struct {
     uint32_t slices;           /* 0 = auto; 1, 2, 4, 8, 16, 32: pixel blocks of 256 / slices pixels (streaming queue: >= 4) */
-    uint32_t tiles_per_wg;     /* 0 = auto; 1, 2, 4: whole tiles per workgroup for shallow launches (slices == 1) */
+    uint32_t tiles_per_wg;     /* 0 = auto; 1, 2, 4: whole tiles per workgroup for shallow launches (2 and 4 imply slices = 1) */
     int32_t queue;             /* -1 = auto; 0 = a lane owns a pixel (no parked samples); 1 = block queue (a workgroup per pixel
-                                * block; what auto picks for more than one ray per pixel); 2 = streaming queue (persistent
+                                * block; what auto picks, since round 2 also for one ray per pixel); 2 = streaming queue (persistent
                                 * workgroups claim pixel blocks and park sample values in a small ring, in LDS when it fits) */
     int32_t phase_vote;        /* -1 = auto; 0 = off; n = longest wait in iterations (sphere-only builds) */
     int32_t kernel_variant;    /* BT_KERNEL_DEFAULT / _LANES / _SORTED, per handle */
@@ -227,8 +227,8 @@ int bt_scene_get_tuning(const bt_scene *scene, bt_tuning *out);
 
 /* Two bit-identical implementations of the render kernel exist:
  * BT_KERNEL_LANES  -- path state in registers; a workgroup owns a block of pixels and deals their samples to its lanes
- *                     through an LDS work queue, or a lane owns a pixel for very shallow launches (default, fastest
- *                     measured);
+ *                     through an LDS work queue (default, fastest measured; a lane owns a pixel only on request,
+ *                     bt_tuning.queue = 0, or when no scratch memory can be had);
  * BT_KERNEL_SORTED -- path state in LDS, the workgroup re-sorts its 256 paths by pending event kind
  *                     every iteration (ballot / prefix-sum compaction).  Selected per scene handle through
  *                     bt_tuning.kernel_variant; BT_KERNEL_DEFAULT is the built-in choice (LANES). */
