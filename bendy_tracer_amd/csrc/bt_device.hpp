@@ -359,7 +359,20 @@ BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int las
 // float2 lanes (v_pk_add_f32 / v_pk_mul_f32, the pair's constants straight from SGPR pairs) -- the same IEEE
 // operations in the same order per sphere as sphere_t() -- then each sphere's root selection runs against the running
 // clip, first sphere first, exactly as the one-at-a-time loop does.
+#ifndef BT_PK_PAIRS
+#define BT_PK_PAIRS 0          // 1: the two-sphere / two-row arithmetic in v_pk_* instructions (round 1; slower since the kernels are register-bound: profiles/r03c/ab_nopk.log)
+#endif
+#if BT_PK_PAIRS
 typedef float f2 __attribute__((ext_vector_type(2)));
+BT_DEV f2 splat2(float v) { return (f2)(v); }
+#else
+struct f2 { float x, y; };
+BT_DEV f2 splat2(float v) { return f2{v, v}; }
+BT_DEV f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+BT_DEV f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+BT_DEV f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+BT_DEV f2 operator*(f2 a, float b) { return f2{a.x * b, a.y * b}; }
+#endif
 template <bool VOLS>
 BT_DEV HitRec intersect_spheres(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object) {
     HitRec h;
@@ -373,7 +386,7 @@ BT_DEV HitRec intersect_spheres(const BtLaunch &P, V3 o, V3 d, float tmin, float
     for (int i = 0; i < n; i += 2) {
         PairK &Q = pairs[i >> 1];               // wave-uniform index -> scalar loads
         const f2 cx = {Q.cx[0], Q.cx[1]}, cy = {Q.cy[0], Q.cy[1]}, cz = {Q.cz[0], Q.cz[1]}, r = {Q.radius[0], Q.radius[1]};
-        const f2 ocx = (f2)(o.x) - cx, ocy = (f2)(o.y) - cy, ocz = (f2)(o.z) - cz;
+        const f2 ocx = splat2(o.x) - cx, ocy = splat2(o.y) - cy, ocz = splat2(o.z) - cz;
         const f2 half_b = (ocx * d.x + ocy * d.y) + ocz * d.z;
         const f2 cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r * r;
         const f2 disc = half_b * half_b - cc;

@@ -62,11 +62,11 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 // measured best once the camera block stopped living in SGPRs (profiles/r01d/ab_w678.log: C3 4.69 / 4.52 / 4.77 /
 // 5.48 ms at 5 / 6 / 7 / 8 waves; Cornell 15.6 / 15.0 / 14.7 / 14.6); round 1b had settled on 5 (96 VGPRs).
 #ifndef BT_WAVES_PER_SIMD
-#define BT_WAVES_PER_SIMD 6
+#define BT_WAVES_PER_SIMD 7              // VGPR budget 72 (round 2, without the SLP vectorizer; profiles/r03c/ab_waves_noslp.log)
 #endif
 #ifndef BT_WAVES_PER_SIMD_RECTS
-#define BT_WAVES_PER_SIMD_RECTS 6      // round 1 built the rect scenes for a seventh wave (72 VGPRs, 64 B of spills); with round 2's cheaper
-#endif                                 // TRACE the spills cost more than the wave hides: Cornell 7.76 -> 7.66 ms at 6 (profiles/r02l/ab_waves_r6_r5v5.log)
+#define BT_WAVES_PER_SIMD_RECTS 7      // 72 VGPRs: round 1's choice (with 64 B of spills), 6 in the middle of round 2 (spills cost more
+#endif                                 // than the wave hid, profiles/r02l), 7 again without the SLP vectorizer: 73 -> 72 VGPRs, Cornell -1 %
 #ifndef BT_WAVES_PER_SIMD_LENS
 #define BT_WAVES_PER_SIMD_LENS 6       // lens builds: 80 VGPRs + ~100 B of scratch per lane still beat 4 waves without
 #endif                                 // scratch (665 -> 719 Msamples/s, profiles/r01g/ab_lens_waves.log)

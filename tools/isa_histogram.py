@@ -124,7 +124,7 @@ def main():
     asm = args.asm
     if not asm:
         asm = os.path.join(tempfile.mkdtemp(prefix="bt_isa_"), "bt_kernels.s")
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-S",
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-S",
                                "--cuda-device-only", "-o", asm,
                                os.path.join(ROOT, "bendy_tracer_amd", "csrc", "bt_kernels.hip")],
                               stderr=subprocess.DEVNULL)

@@ -28,7 +28,7 @@ def main():
     asm = sys.argv[sys.argv.index("--asm") + 1] if "--asm" in sys.argv else None
     if not asm:
         asm = os.path.join(tempfile.mkdtemp(prefix="bt_isa_"), "bt_kernels.s")
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-S", "--cuda-device-only",
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-S", "--cuda-device-only",
                                "-o", asm, os.path.join(ROOT, "bendy_tracer_amd", "csrc", "bt_kernels.hip")], stderr=subprocess.DEVNULL)
 
     def c(name, w="W7"):
