@@ -64,6 +64,9 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #ifndef BT_WAVES_PER_SIMD
 #define BT_WAVES_PER_SIMD 7              // VGPR budget 72 (round 2, without the SLP vectorizer; profiles/r03c/ab_waves_noslp.log)
 #endif
+#ifndef BT_WAVES_PER_SIMD_VOLS
+#define BT_WAVES_PER_SIMD_VOLS BT_WAVES_PER_SIMD     // sphere scenes with volumes (own knob for A/B runs)
+#endif
 #ifndef BT_WAVES_PER_SIMD_RECTS
 #define BT_WAVES_PER_SIMD_RECTS 7      // 72 VGPRs: round 1's choice (with 64 B of spills), 6 in the middle of round 2 (spills cost more
 #endif                                 // than the wave hid, profiles/r02l), 7 again without the SLP vectorizer: 73 -> 72 VGPRs, Cornell -1 %
@@ -108,11 +111,13 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 #endif
 #if BT_NUM_SGPR > 0
 #define BT_SGPR_ATTR __attribute__((amdgpu_num_sgpr(BT_NUM_SGPR)))
+#elif defined(BT_WAVES_EXACT)          // A/B knob: min = max waves per SIMD, so that the SGPR budget is that of BT_WAVES_EXACT waves
+#define BT_SGPR_ATTR __attribute__((amdgpu_waves_per_eu(BT_WAVES_EXACT, BT_WAVES_EXACT)))
 #else
 #define BT_SGPR_ATTR
 #endif
 template <int OUTPUT, bool LENS, int QMODE, bool RECTS, bool VOLS>
-__global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : BT_WAVES_PER_SIMD)) BT_SGPR_ATTR void bt_render_kernel(BtLaunch P) {
+__global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : (VOLS ? BT_WAVES_PER_SIMD_VOLS : BT_WAVES_PER_SIMD))) BT_SGPR_ATTR void bt_render_kernel(BtLaunch P) {
     constexpr bool SLICED = QMODE != 0;    // samples come from a work queue and are parked for the ordered sum
 #ifdef BT_XCCSTAT
     const unsigned long long xcc_t0 = wall_clock64();
