@@ -463,7 +463,10 @@ def main():
             roof["achieved"] = round(d["valu_per_simd_cycle"], 4) if "valu_per_simd_cycle" in d else None
             roof["frac"] = round(d["valu_issue_frac"], 4) if "valu_issue_frac" in d else None
             roof["lane_weighted_frac"] = round(d["valu_lane_weighted_frac"], 4) if "valu_lane_weighted_frac" in d else None
-            roof["issue_cost_weighted_frac"] = round(d["valu_issue_weighted_frac"], 4) if "valu_issue_weighted_frac" in d else None
+            # two prices per PMC opcode class (profiles/valu_issue_costs.json): the opcode in a stream of its own -- an upper
+            # bound that can exceed 1 -- and the opcode among other instructions, where the microbenchmark measured that
+            roof["issue_cost_weighted_frac"] = round(d["valu_issue_mixed_frac"], 4) if "valu_issue_mixed_frac" in d else None
+            roof["issue_cost_pure_stream_bound"] = round(d["valu_issue_weighted_frac"], 4) if "valu_issue_weighted_frac" in d else None
             roof["lanes_active_per_valu_inst"] = round(d["lanes_active"], 4) if "lanes_active" in d else None
             roof["scalar_insts_per_cu_cycle"] = round(d["scalar_per_cu_cycle"], 4) if "scalar_per_cu_cycle" in d else None
             if "hbm_bytes" in d:
@@ -481,8 +484,9 @@ def main():
                          "note": "SURVEY 8(d) wavefront byte model (128 B per path segment + 16 B per pixel) over kernel time / "
                                  "8 TB/s; NOT traffic of this kernel, which keeps ray state in registers -- see `traffic`"}
         roof["note"] = ("VALU-bound path tracer: frac = measured wave64 VALU instructions per SIMD-cycle / 0.5; "
-                        "issue_cost_weighted_frac weights the PMC opcode classes with the issue cycles measured by "
-                        "tools/valu_microbench.hip (profiles/valu_issue_costs.json); hbm_measured_frac = PMC bytes / kernel time / 8 TB/s")
+                        "issue_cost_weighted_frac weights the PMC opcode classes with the mixed-stream issue cycles measured by "
+                        "tools/valu_microbench.hip (profiles/valu_issue_costs.json; issue_cost_pure_stream_bound: every opcode at the cost of a "
+                        "stream of its own, an upper bound that can exceed 1); hbm_measured_frac = PMC bytes / kernel time / 8 TB/s")
         out["roofline"] = roof
         if verified is not None:
             out["verified_vs_single_rank"] = verified

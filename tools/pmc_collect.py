@@ -70,9 +70,9 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def class_costs():
+def class_costs(key="class_cost"):
     try:
-        return {**DEFAULT_CLASS_COST, **json.load(open(os.path.join(ROOT, "profiles", "valu_issue_costs.json")))["class_cost"]}
+        return {**DEFAULT_CLASS_COST, **json.load(open(os.path.join(ROOT, "profiles", "valu_issue_costs.json")))[key]}
     except Exception:
         return dict(DEFAULT_CLASS_COST)
 
@@ -166,6 +166,9 @@ def derive(m):
             d["valu_issue_cycles_weighted"] = weighted
             d["valu_issue_weighted_frac"] = weighted / (N_SIMD * cyc)
             d["mean_issue_cycles_per_valu_inst"] = weighted / m["SQ_INSTS_VALU"]
+            mixed_cost = class_costs("class_cost_mixed")        # mixed-stream opcode costs (tools/make_issue_costs.py)
+            mixed = sum(v * mixed_cost.get(k, 2.0) for k, v in cls.items()) + other * mixed_cost["OTHER"]
+            d["valu_issue_mixed_frac"] = mixed / (N_SIMD * cyc)
     if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
         d["lanes_active"] = m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"])
         if "valu_issue_frac" in d:

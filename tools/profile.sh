@@ -25,6 +25,6 @@ json.dump(out, open("$OUT/pmc_live.json", "w"), indent=1)
 for w, d in out.items():
     x = d["derived"]
     print(f"{w:12s} sha {d['source_sha']} kernel {d['cli']['kernel_ms_under_profiler']:.3f} ms (under the profiler)  VALU/SIMD-cycle {x['valu_per_simd_cycle']:.3f}  lanes {x['lanes_active']:.3f}  "
-          f"weighted {x.get('valu_issue_weighted_frac', 0):.3f}  scalar/CU-cycle {x['scalar_per_cu_cycle']:.3f}  HBM {x['hbm_bytes']/1e9:.3f} GB")
+          f"mixed-cost {x.get('valu_issue_mixed_frac', 0):.3f} (pure-stream bound {x.get('valu_issue_weighted_frac', 0):.3f})  scalar/CU-cycle {x['scalar_per_cu_cycle']:.3f}  HBM {x['hbm_bytes']/1e9:.3f} GB")
 PY
 head -5 $OUT/kernel_stats.csv
