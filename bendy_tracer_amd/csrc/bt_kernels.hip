@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
 
     // the lane's current pixel and sample: fixed pixel / k = 0, 1, ... when !SLICED, taken from the queue when SLICED
     uint32_t px, py, pixel_index, k = 0;
-    Parked *park = nullptr;                            // block queue: where the current sample's value goes
+    uint32_t park_i = 0;                               // block queue: the current item's number i = k * pxb + pixel; its value is
+                                                       // parked at scratch[block * T * pxb + i] (32 bits instead of a pointer: one VGPR less)
     // STREAM: the lane's item -- unit (sequence number in this workgroup's walk), place in the ring, state bits
     uint32_t my_unit = 0, park_idx = 0, item_flags = 0;    // flags: 1 finished (to be counted), 2 reserved (waits for its ring slot), 4 last chunk
     const uint32_t ring_items = STREAM ? (uint32_t)P.ring_slots * P.unit_cap : 0u;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             acc = acc + value;
             k += 1;
         } else if (!STREAM) {
-            *park = Parked{value.x, value.y, value.z};
+            ((Parked *)P.scratch + (size_t)bi * n_items)[park_i] = Parked{value.x, value.y, value.z};
         } else {
             if (P.ring_lds) {
                 float *dst = ring_l + 3u * park_idx;
@@ -783,8 +784,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     const uint32_t i = base + below;
                     if (i >= n_items) break;                              // the block's samples are all taken
                     const uint32_t q = i & (pxb - 1);
-                    k = i >> LOG_PXB_ALL;                                 // pxb is a power of two
-                    const PixelRef r = locate(q);
+                    const PixelRef r = locate(q);                         // (the sample number is park_i >> log2(pxb), see k_cur)
                     px = r.px;
                     py = r.py;
                     if (!r.in_frame) {
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                         continue;
                     }
                     pixel_index = py * P.width + px;
-                    park = (Parked *)P.scratch + ((size_t)bi * T + k) * pxb + q;
+                    park_i = i;
                 }
             }
         }
@@ -801,7 +801,9 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         BT_LS(2, __ballot(ev == EV_GEN)); BT_LS(3, __ballot(ev == EV_DIFFUSE)); BT_LS(4, __ballot(ev == EV_METALLIC));
         BT_LS(5, __ballot(ev == EV_GLASS)); BT_LS(6, __ballot(ev == EV_VOLUME));
         // ---- the lane's one random event of this iteration (numerics contract N6) ----
-        const uint32_t sample_index = sample0 + k;
+        // block queue: the item's sample number comes out of its item number (one register less than keeping both)
+        const uint32_t k_cur = SLICED && !STREAM ? park_i >> LOG_PXB_ALL : k;
+        const uint32_t sample_index = sample0 + k_cur;
         const U4 u = philox(pixel_index, sample_index, ev == EV_GEN ? 0u : event, 0u, P.seed_lo, P.seed_hi);
         // slots of the two angular draws: Metallic [0],[1]; Glass [1],[2]; everything else [2],[3]
         const uint32_t w1 = ev == EV_METALLIC ? u.x : (ev == EV_GLASS ? u.y : u.z);
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             float u_sub = 0.0f, v_sub = 0.0f;
             if (P.subsample_n > 1) {
                 const uint32_t n = (uint32_t)P.subsample_n;
-                const uint32_t subpx = k % (n * n);
+                const uint32_t subpx = k_cur % (n * n);
                 const float width_sub = 1.0f / (float)n;
                 u_sub = (float)(subpx % n) * width_sub;
                 v_sub = (float)(subpx / n) * width_sub;
