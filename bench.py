@@ -4,6 +4,11 @@
     python bench.py --gpus N --steps K --warmup W [--workload C3] [--scaling weak|strong] [--backend nccl|rccl-abi|gloo]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: typed from a bare shell (no WORLD_SIZE in the environment) the first one starts the second as a
+CHILD process -- one rank per GPU, rendezvous on 127.0.0.1 at a free port -- relays rank 0's JSON line and exits with the
+child's return code (no exec: the parent has not touched the GPU and never does).  `--print-launch` prints that command
+as JSON instead of running it.
+
 Workload (BASELINE.json metric "Msamples/s (pixels x spp / s) at 1080p", config C3): scene.json.gz, 1920x1080,
 Subsample::None, Config = main.rs values.  One "step" is one Tracer::render call that adds `samples` rays per pixel
 to a frame that stays resident in HBM (the reference's progressive pattern, main.rs:245-254; step i uses
@@ -21,7 +26,12 @@ exchange, is inside the timed region.
   --backend nccl   torch.distributed's RCCL; rccl-abi = the library's own bt_comm_* entry points (the exchange a
                    non-Python host would call); gloo = rehearsal on a box with fewer GPUs than ranks.
 
-One JSON line on rank 0.  `roofline` (N = 1): the kernel is VALU-bound, so `achieved` / `peak` are wave64 VALU
+N > 1 lines carry what a reader needs to check them: `ranks_joined` (the process group's size after init), `devices` (one
+entry per rank: device index, name, PCI bus id, host pid), `verified_vs_single_rank` (by default one extra, untimed step is
+rendered sharded + exchanged and compared bit for bit with the same step rendered by one rank alone; --no-verify skips it,
+--verify-all compares the whole accumulated run instead) and a `roofline` measured on rank 0's own shard launch.
+
+One JSON line on rank 0.  `roofline`: the kernel is VALU-bound, so `achieved` / `peak` are wave64 VALU
 instructions per SIMD-cycle (peak 0.5: MI355X_MICROARCH.md, 2 cycles per instruction on a SIMD-32), with the HBM
 bytes (`traffic`) and every counter MEASURED IN THIS RUN by rocprofv3 --pmc passes over the same workload
 (tools/pmc_collect.py; separate passes, FETCH_SIZE doubled per the guide) -- unless rocprofv3 is unavailable, then the
@@ -30,12 +40,15 @@ committed summary profiles/pmc_live.json is quoted and flagged `stale` when its 
 cores on a bounded sample of the same workload.
 
 `other_configs` (N = 1 only; not part of `value`): a few renders each of BASELINE.json's other configurations on this GPU
--- C2, C4, C5 rendered whole on one GPU, the 1080p Cornell box -- with wall and kernel time per `Tracer::render`.
+-- C2, C4, C5 rendered whole on one GPU, the 1080p Cornell box -- with wall and kernel time per `Tracer::render`; C2 and C4
+also carry their own PMC-derived fractions (`roofline`), measured in this run like C3's.
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -126,25 +139,72 @@ def parity_figure(b, torch, scene_name, w=240, h=135, spp=16):
                     "seeds from OS entropy); whole frames at the BASELINE sizes are compared in tests/test_gpu_parity.py"}
 
 
-def measure_pmc(workload):
+def measure_pmc(workload, shard=None, spp=None, calls=4):
     """rocprofv3 --pmc passes over this workload, run as child processes BEFORE this process touches the GPU
-    (tools/pmc_collect.py; the profiled program is the C++ CLI over the same library).  Falls back to the committed
-    summary, flagged with whether it was taken on this source tree."""
+    (tools/pmc_collect.py; the profiled program is the C++ CLI over the same library).  shard = (rank, world): one rank's
+    launch of a sharded job.  Falls back to the committed summary, flagged with whether it was taken on this source tree."""
     import pmc_collect
     try:
-        res = pmc_collect.collect(workload, calls=4, passes=("fetch", "write", "sq", "classes"))
+        res = pmc_collect.collect(workload, calls=calls, passes=("fetch", "write", "sq", "classes"), shard=shard, spp=spp)
         res["measured"] = "in this run (rocprofv3 --pmc, separate passes: FETCH_SIZE | WRITE_SIZE | SQ | VALU classes)"
         res["stale"] = False
         return res
     except Exception as e:                                     # no rocprofv3, no counters for this user, ...
         why = str(e)[:300]
     try:
-        res = json.load(open(PMC_CACHE))[workload]
+        key = workload if not shard or shard[1] == 1 else f"{workload}_shard{shard[1]}"
+        res = json.load(open(PMC_CACHE))[key]
         res["measured"] = f"profiles/pmc_live.json (live measurement unavailable: {why})"
         res["stale"] = res.get("source_sha") != pmc_collect.source_hash()
         return res
     except Exception:
         return {"measured": f"unavailable: {why}", "stale": None, "mean_per_launch": {}, "derived": {}}
+
+
+def cached_pmc(workload):
+    """--no-pmc: the committed summary, flagged stale when its source hash differs from this tree."""
+    try:
+        import pmc_collect
+        pmc = json.load(open(PMC_CACHE))[workload]
+        pmc["measured"] = "profiles/pmc_live.json (--no-pmc)"
+        pmc["stale"] = pmc.get("source_sha") != pmc_collect.source_hash()
+        return pmc
+    except Exception:
+        return None
+
+
+def pmc_fractions(pmc, k_ms):
+    """The PMC-derived part of a `roofline` object (the same keys for every configuration).  Three prices for the VALU
+    issue slots in use: `frac` = every wave64 instruction at 2 cycles (the guide's plain rate, a lower bound);
+    `issue_cost_guide_frac` = the guide's price list (2 plain, 4 transcendental and half-rate integer);
+    `issue_cost_weighted_frac` = this repo's own microbenchmark (profiles/valu_issue_costs.json), the upper end.
+    `fp32_flop_frac` = FP32 operations actually performed (ADD + MUL + 2 FMA + TRANS, active lanes only) over the 157.3 TF/s
+    vector peak."""
+    r = {}
+    if not pmc or not pmc.get("derived"):
+        return r
+    d, m = pmc["derived"], pmc.get("mean_per_launch", {})
+    rnd = lambda k: round(d[k], 4) if k in d else None
+    r["achieved"] = rnd("valu_per_simd_cycle")
+    r["frac"] = rnd("valu_issue_frac")
+    r["lane_weighted_frac"] = rnd("valu_lane_weighted_frac")
+    r["issue_cost_guide_frac"] = rnd("valu_issue_guide_frac")
+    r["issue_cost_weighted_frac"] = rnd("valu_issue_mixed_frac")
+    r["issue_cost_pure_stream_bound"] = rnd("valu_issue_weighted_frac")
+    r["fp32_flop_frac"] = rnd("fp32_flop_frac")
+    r["lanes_active_per_valu_inst"] = rnd("lanes_active")
+    r["scalar_insts_per_cu_cycle"] = rnd("scalar_per_cu_cycle")
+    if "hbm_bytes" in d:
+        r["traffic"] = int(d["hbm_bytes"])
+        r["hbm_measured_frac"] = round(d["hbm_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    r["valu_wave_insts_per_launch"] = int(m["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in m else None
+    r["valu_class_counts"] = d.get("valu_class_counts")
+    r["pmc"] = {"measured": pmc.get("measured"), "source_sha": pmc.get("source_sha"), "stale": pmc.get("stale"),
+                "commit": pmc.get("commit"), "kernel_cycles": round(d["kernel_cycles"]) if "kernel_cycles" in d else None,
+                "kernel_ms_under_profiler": pmc.get("cli", {}).get("kernel_ms_under_profiler")}
+    if pmc.get("shard"):
+        r["pmc"]["shard"] = pmc["shard"]
+    return r
 
 
 def lens_extension_rate(b, torch, scene_name, w, h, spp=64, steps=2):
@@ -170,7 +230,7 @@ def lens_extension_rate(b, torch, scene_name, w, h, spp=64, steps=2):
             "note": "extension, not in the reference; fixed-step RK4 on the Schwarzschild null geodesic"}
 
 
-def other_configs(b, torch, steps=3):
+def other_configs(b, torch, steps=3, pmc_by_config=None):
     """The other BASELINE.json configurations on this GPU, a few renders each (they are parity-test cases, not the
     headline; `value` stays C3): per `Tracer::render` the wall time around the call (synchronised) and the kernel time by
     the library's HIP events.  C5 is configs[4]'s frame and depth rendered whole on ONE GPU (its 8-GPU form needs the
@@ -194,9 +254,13 @@ def other_configs(b, torch, steps=3):
             kern.append(sc.last_stats().kernel_ms)
         st = sc.last_stats()
         ms = statistics.mean(wall[1:])
+        k_ms = statistics.mean(kern[1:])
         out[name] = {"workload": f"{scene_name}.json.gz {w}x{h}x{spp}spp", "value": round(w * h * spp / ms / 1e3, 1),
-                     "unit": "Msamples/s", "ms_per_render": round(ms, 4), "kernel_ms": round(statistics.mean(kern[1:]), 4),
-                     "segments_per_sample": round(st.segments / st.samples, 4), "launches": st.launches}
+                     "unit": "Msamples/s", "ms_per_render": round(ms, 4), "kernel_ms": round(k_ms, 4),
+                     "segments_per_sample": round(st.segments / st.samples, 4), "launches": st.launches,
+                     "slices": st.slices, "scratch_bytes": st.scratch_bytes}
+        if pmc_by_config and pmc_by_config.get(name):
+            out[name]["roofline"] = {"bound": "valu", "peak": VALU_PEAK, **pmc_fractions(pmc_by_config[name], k_ms)}
         del buf, sc
     # the reference's interactive loop with its CLI defaults (main.rs:52-65, 245-254): a 768 x 512 window, one
     # Tracer::render per displayed frame with samples = 1 and Subsample::Subpixel(2), scene.json
@@ -290,6 +354,19 @@ class ShardExchange:
         self.shard.view(-1, 4)[:, 3] = 1.0
 
 
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_command(n, argv, port=None):
+    """The command `python bench.py --gpus n ...` starts as a child when it is not already running under a launcher: one
+    process per GPU on this node, rendezvous on the loopback address (the container's hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), os.path.abspath(__file__), *argv]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,33 +383,48 @@ def main():
                          "fewer GPUs than ranks (shards staged through the host)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-overlap", action="store_true", help="run the frame exchange on the render stream")
-    ap.add_argument("--verify", action="store_true", help="compare the gathered frame with a one-rank render of the same steps")
+    ap.add_argument("--verify", action="store_true", help="(default for N > 1) compare one extra sharded + exchanged step with "
+                    "the same step rendered by one rank alone")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the verification step")
+    ap.add_argument("--verify-all", action="store_true", help="compare the whole accumulated frame of warmup + timed steps with a "
+                    "one-rank render of the same steps (costs N x the timed work on every rank)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (process group, shard, all-gather, un-permute) even with one rank")
+    ap.add_argument("--print-launch", action="store_true", help="print the child command a bare `--gpus N` run would start, as JSON, and exit")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.print_launch):
+        # typed from a bare shell: this process becomes the launcher.  It has not imported torch, has not touched the GPU and
+        # never will -- the ranks are CHILD processes (no exec), rank 0's JSON line passes through on the inherited stdout
+        cmd = launch_command(args.gpus, [a for a in sys.argv[1:] if a != "--print-launch"])
+        if args.print_launch:
+            print(json.dumps({"launch": cmd, "cwd": ROOT}))
+            return 0
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+        return subprocess.run(cmd, cwd=ROOT, env=env).returncode
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world                                  # under a launcher the environment is authoritative
     dist_path = world > 1 or args.force_dist          # `dist_path` replaces `world > 1` below
+    scene_name, w, h, base_spp = WORKLOADS[args.workload]
+    spp = base_spp * world if args.scaling == "weak" else base_spp      # weak: fixed work per GPU; strong: fixed total
 
-    # counters first: child processes under rocprofv3, while this process has not initialised the GPU yet
-    pmc = None
-    if world == 1 and rank == 0 and not args.force_dist:
+    # counters first: child processes under rocprofv3, while this process has not initialised the GPU yet.  N = 1: the
+    # headline workload, then C2 and C4 (BASELINE configs[1] and [3]) for `other_configs`.  N > 1: rank 0 measures ITS OWN
+    # shard launch (1/N of the tiles at this run's samples per step) before it joins the process group; the other ranks wait
+    # for it in the rendezvous.
+    pmc, pmc_other = None, {}
+    if rank == 0 and not args.force_dist:
+        shard = (0, world) if world > 1 else None
         if args.no_pmc:
-            try:
-                import pmc_collect
-                pmc = json.load(open(PMC_CACHE))[args.workload]
-                pmc["measured"] = "profiles/pmc_live.json (--no-pmc)"
-                pmc["stale"] = pmc.get("source_sha") != pmc_collect.source_hash()
-            except Exception:
-                pmc = None
+            pmc = cached_pmc(args.workload if world == 1 else f"{args.workload}_shard{world}")
         else:
-            pmc = measure_pmc(args.workload)
+            pmc = measure_pmc(args.workload, shard=shard, spp=spp if world > 1 else None, calls=4 if world == 1 else 3)
+        if world == 1 and args.workload == "C3" and not args.no_other_configs:
+            for name in ("C2", "C4"):
+                pmc_other[name] = cached_pmc(name) if args.no_pmc else measure_pmc(name, calls=6 if name == "C2" else 3)
 
     import torch
     import torch.distributed as dist
@@ -351,9 +443,16 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    census = None
+    if dist_path:
+        # who actually joined: one entry per rank, gathered over the process group that was just formed
+        prop = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": prop.name,
+                "pci_bus_id": getattr(prop, "pci_bus_id", None), "uuid": str(getattr(prop, "uuid", "")) or None,
+                "pid": os.getpid(), "host": socket.gethostname()}
+        census = [None] * dist.get_world_size()
+        dist.all_gather_object(census, mine)
 
-    scene_name, w, h, base_spp = WORKLOADS[args.workload]
-    spp = base_spp * world if args.scaling == "weak" else base_spp      # weak: fixed work per GPU; strong: fixed total
     scene = b.Scene.load(os.path.join(ROOT, "scenes", f"{scene_name}.json.gz"))
     cam = scene.find_by_tag("camera")
     scene.set_camera_aspect(cam, w / h)                     # main.rs:218-223
@@ -402,8 +501,8 @@ def main():
         step(i)
     elapsed, step_ms = timed(args.warmup)
 
-    verified = None
-    if args.verify:
+    verified, verify_mode = None, None
+    if args.verify_all:
         # the frame every rank now holds must equal what one rank renders alone with the same seeds: RNG
         # is keyed by global pixel / sample index, so the image does not depend on the number of ranks
         ref = b.Buffer.new(w, h)
@@ -411,6 +510,28 @@ def main():
             tracer.render(scene, cam, rc, ref, seed=SEED, sample_base=i * spp)
         torch.cuda.synchronize()
         verified = bool(torch.equal(frame.data, ref.data))
+        verify_mode = f"all {args.warmup + args.steps} steps"
+        del ref
+    elif dist_path and (args.verify or not args.no_verify):
+        # default for N > 1: ONE extra step, outside the timed region, rendered sharded + exchanged into a fresh frame and
+        # by this rank alone into another; every rank compares its own gathered copy, the verdict is the AND over the ranks
+        i_v = args.warmup + args.steps
+        keep = ex.shard.clone()
+        ex.reset()
+        got = b.Buffer.new(w, h)
+        tracer.render_shard(scene, cam, rc, ex.shard, w, h, rank, world, seed=SEED, sample_base=i_v * spp)
+        ex.exchange(i_v, frame=got)
+        ex.drain()
+        ref = b.Buffer.new(w, h)
+        tracer.render(scene, cam, rc, ref, seed=SEED, sample_base=i_v * spp)
+        torch.cuda.synchronize()
+        ok = torch.tensor([1 if torch.equal(got.data, ref.data) else 0], dtype=torch.int32,
+                          device="cuda" if args.backend != "gloo" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        verified = bool(int(ok.item()))
+        verify_mode = f"one extra step (sample_base {i_v * spp}, {spp} spp), every rank's gathered copy, AND over ranks"
+        ex.shard.copy_(keep)
+        del got, ref, keep
 
     final_only = None
     if dist_path and args.scaling == "strong":
@@ -458,44 +579,34 @@ def main():
                 "launches_per_step": last.launches, "scratch_bytes": last.scratch_bytes,
                 "render_stream_ms_per_step_timed_region": round(statistics.mean(step_ms), 4),
                 "segments_per_launch": int(seg), "segments_per_sample": round(seg / (my_pixels * spp), 4)}
-        if pmc and pmc.get("derived"):
-            d, m = pmc["derived"], pmc.get("mean_per_launch", {})
-            roof["achieved"] = round(d["valu_per_simd_cycle"], 4) if "valu_per_simd_cycle" in d else None
-            roof["frac"] = round(d["valu_issue_frac"], 4) if "valu_issue_frac" in d else None
-            roof["lane_weighted_frac"] = round(d["valu_lane_weighted_frac"], 4) if "valu_lane_weighted_frac" in d else None
-            # two prices per PMC opcode class (profiles/valu_issue_costs.json): the opcode in a stream of its own -- an upper
-            # bound that can exceed 1 -- and the opcode among other instructions, where the microbenchmark measured that
-            roof["issue_cost_weighted_frac"] = round(d["valu_issue_mixed_frac"], 4) if "valu_issue_mixed_frac" in d else None
-            roof["issue_cost_pure_stream_bound"] = round(d["valu_issue_weighted_frac"], 4) if "valu_issue_weighted_frac" in d else None
-            roof["lanes_active_per_valu_inst"] = round(d["lanes_active"], 4) if "lanes_active" in d else None
-            roof["scalar_insts_per_cu_cycle"] = round(d["scalar_per_cu_cycle"], 4) if "scalar_per_cu_cycle" in d else None
-            if "hbm_bytes" in d:
-                roof["traffic"] = int(d["hbm_bytes"])
-                roof["hbm_measured_frac"] = round(d["hbm_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            roof["valu_wave_insts_per_launch"] = int(m["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in m else None
-            roof["valu_class_counts"] = d.get("valu_class_counts")
-            roof["pmc"] = {"measured": pmc.get("measured"), "source_sha": pmc.get("source_sha"), "stale": pmc.get("stale"),
-                           "commit": pmc.get("commit"), "kernel_cycles": round(d["kernel_cycles"]) if "kernel_cycles" in d else None,
-                           "kernel_ms_under_profiler": pmc.get("cli", {}).get("kernel_ms_under_profiler")}
+        roof.update(pmc_fractions(pmc, k_ms))
         # SURVEY 8(d)'s byte model, kept as a labelled non-headline figure: a wavefront formulation would move these bytes,
         # the shipped register-resident kernel does not
         alg_bytes = BYTES_PER_SEGMENT * seg + BYTES_PER_PIXEL * my_pixels
         roof["model"] = {"bytes_per_launch": int(alg_bytes), "model_frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "note": "SURVEY 8(d) wavefront byte model (128 B per path segment + 16 B per pixel) over kernel time / "
                                  "8 TB/s; NOT traffic of this kernel, which keeps ray state in registers -- see `traffic`"}
-        roof["note"] = ("VALU-bound path tracer: frac = measured wave64 VALU instructions per SIMD-cycle / 0.5; "
-                        "issue_cost_weighted_frac weights the PMC opcode classes with the mixed-stream issue cycles measured by "
-                        "tools/valu_microbench.hip (profiles/valu_issue_costs.json; issue_cost_pure_stream_bound: every opcode at the cost of a "
-                        "stream of its own, an upper bound that can exceed 1); hbm_measured_frac = PMC bytes / kernel time / 8 TB/s")
+        roof["note"] = ("VALU-bound path tracer: frac = measured wave64 VALU instructions per SIMD-cycle / 0.5 (every instruction at "
+                        "the guide's 2 cycles: the lower bound); issue_cost_guide_frac = the guide's prices (2 plain, 4 transcendental "
+                        "and half-rate integer); issue_cost_weighted_frac = the PMC opcode classes x the mixed-stream issue cycles "
+                        "measured by tools/valu_microbench.hip (profiles/valu_issue_costs.json: the upper end; "
+                        "issue_cost_pure_stream_bound prices every opcode as a stream of its own and can exceed 1); fp32_flop_frac = "
+                        "FP32 operations on active lanes / 157.3 TF/s; hbm_measured_frac = PMC bytes / kernel time / 8 TB/s"
+                        + ("; N > 1: counters of rank 0's own shard launch, taken before it joined the process group" if world > 1 else ""))
         out["roofline"] = roof
+        if census is not None:
+            out["ranks_joined"] = dist.get_world_size()
+            out["devices"] = census
+            out["distinct_devices"] = len({(c["host"], c["pci_bus_id"] or c["device"]) for c in census})
         if verified is not None:
             out["verified_vs_single_rank"] = verified
+            out["verify"] = verify_mode
         if final_only is not None:
             out["final_gather_only"] = final_only
         if world == 1 and args.workload == "C3" and not args.force_dist:
             out["lens_extension"] = lens_extension_rate(b, torch, scene_name, w, h)
             if not args.no_other_configs:
-                out["other_configs"] = other_configs(b, torch)
+                out["other_configs"] = other_configs(b, torch, pmc_by_config=pmc_other)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_name, w, h, args.cpu_budget)
             out["parity"] = parity_figure(b, torch, scene_name)
@@ -508,4 +619,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -144,6 +144,7 @@ EXPORTS = [
     "bt_shard_floats", "bt_render_shard_device", "bt_unshard_device", "bt_preview_device", "bt_preview",
     "bt_comm_unique_id", "bt_comm_init", "bt_comm_free", "bt_comm_rank", "bt_comm_world", "bt_allgather_shards_device",
     "bt_exchange_frame_device", "bt_scene_last_stats", "bt_tuning_default", "bt_scene_set_tuning", "bt_scene_get_tuning", "bt_scene_default", "bt_scene_to_json", "bt_scene_save", "bt_write_png",
+    "bt_scene_trim",
 ]
 
 
@@ -204,6 +205,7 @@ def _load():
     L.bt_tuning_default.argtypes = [C.POINTER(_CTuning)]
     L.bt_scene_set_tuning.argtypes = [vp, C.POINTER(_CTuning)]
     L.bt_scene_get_tuning.argtypes = [vp, C.POINTER(_CTuning)]
+    L.bt_scene_trim.argtypes = [vp]
     return L
 
 
@@ -343,6 +345,10 @@ class Scene:
         if knobs:
             self.set_tuning(**knobs)
         return knobs
+
+    def trim(self):
+        """Returns the scratch / cached frame the handle keeps between calls to the device (bt_scene_trim)."""
+        _check(lib.bt_scene_trim(self._h))
 
     def last_stats(self) -> Stats:
         st = Stats()

@@ -74,6 +74,8 @@ struct Args {
     unsigned samples_per_call = 1;                       // main.rs:248 renders 1 sample per displayed frame
     bool no_screenshot = false;
     std::string stats_json;                              // per-call kernel times / segment counts (profiling harness)
+    unsigned shard_rank = 0, shard_world = 1;            // --shard r,w: render rank r's tile shard of a w-rank job (measurement
+                                                         // harness for bench.py --gpus N; no screenshot, the shard is tile-major)
     bool has_lens = false;
     bt_lens lens{};
 };
@@ -83,7 +85,7 @@ void usage() {
                  "usage: bendy-tracer-hip --output <full|albedo|normal> [--width 768] [--height 512] [--samples 64]\n"
                  "       [--subsample 2] [--screenshot screenshots/render.png] [--scene scene.json]\n"
                  "       [--seed N] [--save-scene PATH] [--device N] [--quiet]\n"
-                 "       [--samples-per-call 1] [--no-screenshot] [--stats-json PATH]   (measurement harness)\n"
+                 "       [--samples-per-call 1] [--no-screenshot] [--stats-json PATH] [--shard rank,world]   (measurement harness)\n"
                  "       [--lens x,y,z,rs,step,radius[,max_steps]]   (extension: not in the reference)\n");
 }
 
@@ -113,6 +115,12 @@ Args parse(int argc, char **argv) {
         else if (k == "--samples-per-call") a.samples_per_call = std::max(1u, (unsigned)std::strtoul(val().c_str(), nullptr, 10));
         else if (k == "--no-screenshot") a.no_screenshot = true;
         else if (k == "--stats-json") a.stats_json = val();
+        else if (k == "--shard") {
+            const std::string spec = val();
+            if (std::sscanf(spec.c_str(), "%u,%u", &a.shard_rank, &a.shard_world) != 2 || a.shard_world == 0 || a.shard_rank >= a.shard_world)
+                die("--shard expects rank,world with rank < world");
+            a.no_screenshot = true;
+        }
         else if (k == "--lens") {
             const std::string spec = val();
             float f[7] = {0, 0, 0, 0, 0, 0, 4096};
@@ -183,7 +191,8 @@ int main(int argc, char **argv) {
     const unsigned nn = rc.subsample_n ? rc.subsample_n * rc.subsample_n : 1;
 
     // Buffer::new (buffer.rs:41-50), resident in HBM
-    const size_t n_px = (size_t)args.width * args.height;
+    const bool sharded = args.shard_world > 1;
+    const size_t n_px = sharded ? bt_shard_floats(args.width, args.height, args.shard_world) / 4 : (size_t)args.width * args.height;
     std::vector<float> init(n_px * 4, 0.0f);
     for (size_t i = 0; i < n_px; ++i) init[4 * i + 3] = 1.0f;
     float *d_frame = nullptr;
@@ -201,7 +210,9 @@ int main(int argc, char **argv) {
         rc.samples = std::min(args.samples_per_call, std::max(1u, (args.samples - buffer_samples) / nn));
         rc.sample_base = (buffer_samples + nn - 1) / nn;
         const auto t0 = std::chrono::steady_clock::now();
-        int st = bt_render_device(scene, camera, &cfg, &rc, d_frame, args.width, args.height, args.seed, nullptr);
+        int st = sharded ? bt_render_shard_device(scene, camera, &cfg, &rc, d_frame, args.width, args.height, args.shard_rank,
+                                                  args.shard_world, args.seed, nullptr)
+                         : bt_render_device(scene, camera, &cfg, &rc, d_frame, args.width, args.height, args.seed, nullptr);
         check(st, "bt_render_device");
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
         const double delta = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -34,6 +34,7 @@ namespace {
 thread_local std::string g_error;
 thread_local int g_error_code = 0;
 constexpr uint64_t kDefaultScratchCap = 2ull << 30;   // parked sample values per launch; deeper renders are split
+constexpr uint32_t kScratchShrinkAfter = 8;           // renders in a row that need < 1/4 of the scratch before it shrinks
 int set_error(int code, const std::string &msg) {
     g_error = msg;
     g_error_code = code;
@@ -85,6 +86,7 @@ struct bt_scene {
     unsigned long long *d_counters = nullptr;
     float *d_scratch = nullptr;    // parked sample values of sliced renders
     size_t scratch_bytes = 0;
+    uint32_t scratch_small_streak = 0;   // consecutive renders that needed less than a quarter of the scratch held
     float *d_host_frame = nullptr; // device copy of the caller's host buffer (bt_render), kept between calls
     size_t host_frame_bytes = 0;
     int n_cu = 0;                  // hipDeviceProp_t::multiProcessorCount of `device`
@@ -107,6 +109,7 @@ struct bt_scene {
         d_scratch = nullptr;
         d_host_frame = nullptr;
         scratch_bytes = host_frame_bytes = 0;
+        scratch_small_streak = 0;
         ev_start = ev_stop = nullptr;
         stats_pending = false;
     }
@@ -404,8 +407,14 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     // the launch should hold >= 4 x 20 waves per CU (tuned on the MI355X's 256 CUs as "4 * 5120 waves", round 1d)
     const uint64_t wave_slots = (uint64_t)s->n_cu * 20;
     auto ensure_scratch = [&](uint64_t need) -> bool {
-        // grow when too small; give the memory back when this render needs less than a quarter of what is held
-        if (s->scratch_bytes >= need && s->scratch_bytes / 4 <= need) return true;
+        // Grow when too small.  Give memory back only after kScratchShrinkAfter consecutive renders that each needed less
+        // than a quarter of what is held: a caller that alternates deep renders with shallow previews on one handle keeps
+        // its scratch (no hipFree / hipMalloc -- a device-wide synchronisation -- per call); bt_scene_trim() returns it at once.
+        if (s->scratch_bytes >= need) {
+            if (s->scratch_bytes / 4 <= need) { s->scratch_small_streak = 0; return true; }
+            if (++s->scratch_small_streak < kScratchShrinkAfter) return true;
+        }
+        s->scratch_small_streak = 0;
         if (s->d_scratch) {
             if (hipStreamSynchronize(stream) != hipSuccess) return false;   // an earlier launch on this stream may still read it
             (void)hipFree(s->d_scratch);
@@ -507,7 +516,11 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         };
         bool queue = qmode != 0;
         if (queue) {
-            const uint64_t per_sample = px_launch * nn * 3 * sizeof(float);      // 12 B per parked sample value
+            // 12 B per parked sample value.  A workgroup that owns tiles_per_wg = 2 or 4 whole tiles parks at
+            // workgroup * (256 * tiles_per_wg * T) + item: the last workgroup's slots exist even when the launch's tile count
+            // is not a multiple of tiles_per_wg, so the scratch is sized for the tile count rounded up to a multiple of 4
+            const uint64_t px_parked = (((uint64_t)grid + 3) / 4 * 4) * BT_TILE_DIM * BT_TILE_DIM;
+            const uint64_t per_sample = px_parked * nn * 3 * sizeof(float);
             if (per_sample * chunk > cap) chunk = (uint32_t)std::max<uint64_t>(1, cap / per_sample);
             if (!ensure_scratch(per_sample * chunk)) queue = false;
         }
@@ -862,6 +875,23 @@ int bt_preview(const float *rgba_host, uint8_t *rgba8_host, uint32_t width, uint
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return set_error(BT_ERR_DEVICE, hipGetErrorString(e));
     return rc;
+}
+
+int bt_scene_trim(bt_scene *scene) {
+    if (!scene) return set_error(BT_ERR_INVALID_ARG, "null scene");
+    if (scene->device < 0 || (!scene->d_scratch && !scene->d_host_frame)) return 0;
+    int cur = -1;
+    BT_HIP(hipGetDevice(&cur));
+    if (cur != scene->device) BT_HIP(hipSetDevice(scene->device));
+    BT_HIP(hipDeviceSynchronize());                       // launches that still read the scratch / the cached frame
+    if (scene->d_scratch) (void)hipFree(scene->d_scratch);
+    if (scene->d_host_frame) (void)hipFree(scene->d_host_frame);
+    scene->d_scratch = nullptr;
+    scene->d_host_frame = nullptr;
+    scene->scratch_bytes = scene->host_frame_bytes = 0;
+    scene->scratch_small_streak = 0;
+    if (cur != scene->device) BT_HIP(hipSetDevice(cur));
+    return 0;
 }
 
 int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {

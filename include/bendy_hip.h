@@ -234,6 +234,12 @@ int bt_scene_get_tuning(const bt_scene *scene, bt_tuning *out);
  *                     bt_tuning.kernel_variant; BT_KERNEL_DEFAULT is the built-in choice (LANES). */
 enum { BT_KERNEL_DEFAULT = 0, BT_KERNEL_LANES = 1, BT_KERNEL_SORTED = 2 };
 
+/* Returns the device memory a handle keeps between calls -- the parked sample values of the work queue (bt_stats.scratch_bytes;
+ * it otherwise shrinks only after eight consecutive renders that needed less than a quarter of it) and bt_render's cached copy
+ * of the caller's frame -- to the device (synchronises it).  The reference holds no such state: `Tracer::render` borrows the
+ * scene and the buffer for the call (tracer/mod.rs:179-185).  A handle serves ONE stream at a time, like `&mut Buffer`. */
+int bt_scene_trim(bt_scene *scene);
+
 /* Work counters of the most recent bt_render* call on this handle (synchronises). */
 int bt_scene_last_stats(bt_scene *scene, bt_stats *out);
 

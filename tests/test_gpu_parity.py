@@ -278,12 +278,19 @@ def test_several_tiles_per_workgroup(bendy, oracle, tiles, world):
         tr.render(sc, cam, rc, buf)
         torch.cuda.synchronize()
         assert sc.last_stats().slices == 1 and np.array_equal(buf.numpy(), it)
+        grid = 50
     else:
         shards = []
         for r in range(world):
             s = bendy.new_shard(w, h, world)
             tr.render_shard(sc, cam, rc, s, w, h, r, world)
             shards.append(s)
+        grid = -(-50 // world)
+    # the last workgroup's parking slots exist even when the tile count is not a multiple of tiles_per_wg (150 x 75 has 50
+    # tiles, 17 per rank at world 3): highest index written = workgroups * 256 * tiles * T parked values of 12 bytes
+    workgroups, T = -(-grid // tiles), 4
+    assert sc.last_stats().scratch_bytes >= workgroups * tiles * 256 * T * 12
+    if world != 1:
         out = bendy.Buffer.new(w, h)
         bendy.unshard(torch.cat(shards), out, world)
         torch.cuda.synchronize()
@@ -312,6 +319,41 @@ def test_one_deep_call_equals_many_shallow_calls(bendy):
     for _ in range(32):
         tr.render(sc, cam, bendy.RenderConfig.with_samples(64), buf)
     assert buf.samples == 2048 and np.array_equal(buf.numpy(), deep.numpy())
+
+
+def test_scratch_is_kept_between_deep_and_shallow_renders_and_trimmed_on_request(bendy, oracle):
+    """The parked sample values live in scratch memory on the handle (bt_stats.scratch_bytes).  A caller that alternates deep
+    renders with shallow previews keeps it -- it shrinks only after eight shallow renders in a row -- and bt_scene_trim()
+    returns it at once; the pixels never depend on it."""
+    import torch
+    w, h = 160, 96
+    sc, cam = gpu_scene(bendy, "scene", w, h)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    buf = bendy.Buffer.new(w, h)
+    deep, shallow = bendy.RenderConfig.with_samples(64), bendy.RenderConfig.with_samples(2)
+    tr.render(sc, cam, deep, buf, sample_base=0)
+    held = sc.last_stats().scratch_bytes
+    assert held >= w * h * 64 * 12
+    for i in range(3):                                         # deep / shallow alternation: nothing is freed
+        tr.render(sc, cam, shallow, buf, sample_base=64 + 66 * i)
+        assert sc.last_stats().scratch_bytes == held
+        tr.render(sc, cam, deep, buf, sample_base=66 + 66 * i)
+        assert sc.last_stats().scratch_bytes == held
+    base = 64 + 66 * 3
+    sizes = []
+    for i in range(9):                                         # shallow renders only: the eighth in a row shrinks it
+        tr.render(sc, cam, shallow, buf, sample_base=base + 2 * i)
+        sizes.append(sc.last_stats().scratch_bytes)
+    assert sizes[:7] == [held] * 7 and sizes[7] < held // 4 and sizes[8] == sizes[7]
+    tr.render(sc, cam, deep, buf, sample_base=base + 18)
+    assert sc.last_stats().scratch_bytes == held
+    sc.trim()
+    tr.render(sc, cam, shallow, buf, sample_base=base + 18 + 64)
+    assert sc.last_stats().scratch_bytes == sizes[7]
+    torch.cuda.synchronize()
+    total = base + 18 + 64 + 2
+    it, _ = oracle_render(oracle, "scene", w, h, total)
+    assert buf.samples == total and np.array_equal(buf.numpy(), it)
 
 
 def test_render_deeper_than_the_scratch_is_split_into_launches(bendy, oracle):

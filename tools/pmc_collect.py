@@ -53,6 +53,11 @@ PASSES = {
 N_SIMD = 1024          # MI355X: 256 CUs x 4 SIMD-32
 VALU_PEAK = 0.5        # wave64 instructions per SIMD-cycle (MI355X_MICROARCH.md: 2 cycles each)
 HBM_PEAK = 8.0e12      # bytes/s (spec; ~6.3e12 achievable)
+FP32_PEAK = 157.3e12   # flop/s, vector FP32 (MI355X_MICROARCH.md): 256 CUs x 128 lanes x 2 (FMA) x 2.4 GHz
+FP32_CLOCK_HZ = 2.4e9
+# the guide's prices per wave64 instruction: 2 cycles plain, 4 for transcendental and half-rate integer (64-bit / mul_lo / mul_hi)
+GUIDE_CLASS_COST = {"ADD_F32": 2.0, "MUL_F32": 2.0, "FMA_F32": 2.0, "TRANS_F32": 4.0, "INT32": 2.0, "INT64": 4.0, "CVT": 2.0,
+                    "OTHER": 2.0}
 # issue cycles per wave64 instruction by PMC class; replaced by profiles/valu_issue_costs.json when it exists
 DEFAULT_CLASS_COST = {"ADD_F32": 2.0, "MUL_F32": 2.0, "FMA_F32": 2.0, "TRANS_F32": 4.0, "INT32": 2.0, "INT64": 8.0, "CVT": 2.0,
                       "OTHER": 2.0}
@@ -77,13 +82,18 @@ def class_costs(key="class_cost"):
         return dict(DEFAULT_CLASS_COST)
 
 
-def cli_command(workload, calls, stats_path=None):
-    scene, w, h, spp = WORKLOADS[workload]
+def cli_command(workload, calls, stats_path=None, shard=None, spp=None):
+    """shard = (rank, world): the launch of ONE rank of a `world`-rank job (its interleaved tiles, bench.py --gpus N);
+    spp overrides the workload's samples per launch (weak scaling: 64 * N)."""
+    scene, w, h, spp0 = WORKLOADS[workload]
+    spp = spp or spp0
     cmd = [CLI, "--output", "full", "--width", str(w), "--height", str(h), "--subsample", "1", "--samples", str(spp * calls),
            "--samples-per-call", str(spp), "--scene", os.path.join(ROOT, "scenes", f"{scene}.json.gz"), "--no-screenshot",
            "--quiet"]
     if stats_path:
         cmd += ["--stats-json", stats_path]
+    if shard and shard[1] > 1:
+        cmd += ["--shard", f"{shard[0]},{shard[1]}"]
     return cmd
 
 
@@ -115,14 +125,14 @@ def run_pass(counters, cmd, workdir, timeout=300):
     return out, meta
 
 
-def collect(workload, calls=4, passes=("fetch", "write", "sq", "classes"), keep=None):
+def collect(workload, calls=4, passes=("fetch", "write", "sq", "classes"), keep=None, shard=None, spp=None):
     """Runs the passes; -> dict with per-launch means, derived figures, kernel meta and the source hash."""
     tmp = keep or tempfile.mkdtemp(prefix="bt_pmc_")
     os.makedirs(tmp, exist_ok=True)
     stats_path = os.path.join(tmp, "cli_stats.json")
     means, meta, launches = {}, {}, {}
     for name in passes:
-        vals, m = run_pass(PASSES[name], cli_command(workload, calls, stats_path), os.path.join(tmp, name))
+        vals, m = run_pass(PASSES[name], cli_command(workload, calls, stats_path, shard, spp), os.path.join(tmp, name))
         meta = m or meta
         for k, v in vals.items():
             v = v[1:] if len(v) > 1 else v            # the first launch pays scratch allocation / cold caches
@@ -130,6 +140,8 @@ def collect(workload, calls=4, passes=("fetch", "write", "sq", "classes"), keep=
             launches[k] = len(v)
     res = {"workload": workload, "source_sha": source_hash(), "kernel": meta, "launches_averaged": launches,
            "mean_per_launch": means}
+    if shard and shard[1] > 1:
+        res["shard"] = {"rank": shard[0], "world": shard[1], "samples_per_launch": spp or WORKLOADS[workload][3]}
     try:
         st = json.load(open(stats_path))["calls"]
         st = st[1:] if len(st) > 1 else st
@@ -138,6 +150,10 @@ def collect(workload, calls=4, passes=("fetch", "write", "sq", "classes"), keep=
     except Exception:
         pass
     res["derived"] = derive(means)
+    d = res["derived"]
+    if "fp32_flops" in d and res.get("cli", {}).get("kernel_ms_under_profiler") and "kernel_cycles" in d:
+        # flop rate at the clock the counters ran at: flops per kernel cycle x the 2.4 GHz the peak is quoted at
+        d["fp32_flop_frac"] = d["fp32_flops"] / d["kernel_cycles"] * FP32_CLOCK_HZ / FP32_PEAK
     if keep is None:
         shutil.rmtree(tmp, ignore_errors=True)
     return res
@@ -169,10 +185,16 @@ def derive(m):
             mixed_cost = class_costs("class_cost_mixed")        # mixed-stream opcode costs (tools/make_issue_costs.py)
             mixed = sum(v * mixed_cost.get(k, 2.0) for k, v in cls.items()) + other * mixed_cost["OTHER"]
             d["valu_issue_mixed_frac"] = mixed / (N_SIMD * cyc)
+            guide = sum(v * GUIDE_CLASS_COST.get(k, 2.0) for k, v in cls.items()) + other * GUIDE_CLASS_COST["OTHER"]
+            d["valu_issue_guide_frac"] = guide / (N_SIMD * cyc)
     if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
         d["lanes_active"] = m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"])
         if "valu_issue_frac" in d:
             d["valu_lane_weighted_frac"] = d["valu_issue_frac"] * d["lanes_active"]
+        if all(("SQ_INSTS_VALU_" + k) in m for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32")):
+            # FP32 operations actually performed: (ADD + MUL + 2 FMA + TRANS) wave instructions x 64 lanes x the share of lanes active
+            d["fp32_flops"] = (m["SQ_INSTS_VALU_ADD_F32"] + m["SQ_INSTS_VALU_MUL_F32"] + 2.0 * m["SQ_INSTS_VALU_FMA_F32"] +
+                               m["SQ_INSTS_VALU_TRANS_F32"]) * 64.0 * d["lanes_active"]
     if "SQ_WAVES" in m:
         for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"):
             if k in m:
@@ -191,9 +213,12 @@ def main():
     ap.add_argument("--calls", type=int, default=4)
     ap.add_argument("--passes", default="fetch,write,sq,classes,waits")
     ap.add_argument("--out")
+    ap.add_argument("--shard", default=None, help="rank,world: one rank's launch of a sharded job")
+    ap.add_argument("--spp", type=int, default=None, help="samples per launch (default: the workload's)")
     ap.add_argument("--commit", default=None, help="git commit hash to stamp into the summary (tools/profile.sh)")
     args = ap.parse_args()
-    res = collect(args.workload, args.calls, tuple(args.passes.split(",")))
+    shard = tuple(int(x) for x in args.shard.split(",")) if args.shard else None
+    res = collect(args.workload, args.calls, tuple(args.passes.split(",")), shard=shard, spp=args.spp)
     if args.commit:
         res["commit"] = args.commit
     text = json.dumps(res, indent=1)
