@@ -123,13 +123,12 @@ class _CRenderConfig(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("pixels", C.c_uint64), ("kernel_ms", C.c_float),
                 ("lens_steps", C.c_uint64), ("slices", C.c_uint32), ("launches", C.c_uint32),
-                ("scratch_bytes", C.c_uint64), ("parked_bytes", C.c_uint64)]
+                ("scratch_bytes", C.c_uint64), ("parked_bytes", C.c_uint64), ("queue", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class _CTuning(C.Structure):  # include/bendy_hip.h `bt_tuning`
-    _fields_ = [("slices", C.c_uint32), ("tiles_per_wg", C.c_uint32), ("queue", C.c_int32), ("phase_vote", C.c_int32),
-                ("kernel_variant", C.c_int32), ("park", C.c_int32), ("scratch_cap_bytes", C.c_uint64),
-                ("workgroups_per_cu", C.c_uint32), ("ring_slots", C.c_uint32)]
+    _fields_ = [("slices", C.c_uint32), ("queue", C.c_int32), ("phase_vote", C.c_int32), ("workgroups_per_cu", C.c_uint32),
+                ("scratch_cap_bytes", C.c_uint64)]
 
 
 class _CLens(C.Structure):
@@ -308,20 +307,16 @@ class Scene:
         _check(lib.bt_scene_export_prims(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), n))
         return out.reshape(-1, 36)
 
-    KERNEL_VARIANTS = {"default": 0, "lanes": 1, "sorted": 2}
-
     def set_tuning(self, **knobs):
         """bt_scene_set_tuning: pins launch-shape knobs of this handle (tests and A/B tools; none of them changes a
-        pixel).  Keywords = fields of `bt_tuning` (slices, tiles_per_wg, queue, phase_vote, kernel_variant -- a name
-        or a number --, park, scratch_cap_bytes); fields not named keep their current value; no keywords = defaults."""
+        pixel).  Keywords = fields of `bt_tuning` (slices, queue, phase_vote, workgroups_per_cu, scratch_cap_bytes);
+        fields not named keep their current value; no keywords = defaults."""
         t = _CTuning()
         if not knobs:
             _check(lib.bt_scene_set_tuning(self._h, None))
             return
         _check(lib.bt_scene_get_tuning(self._h, C.byref(t)))
         for k, v in knobs.items():
-            if k == "kernel_variant" and isinstance(v, str):
-                v = self.KERNEL_VARIANTS[v]
             if not hasattr(t, k):
                 raise TypeError(f"bt_tuning has no field {k!r}")
             setattr(t, k, int(v))
@@ -333,15 +328,12 @@ class Scene:
         return {k: getattr(t, k) for k, _ in _CTuning._fields_}
 
     def tuning_from_env(self, environ=None):
-        """Developer convenience for tools/ and tests/: BT_SLICES, BT_TILES_PER_WG, BT_QUEUE, BT_PHASE_VOTE, BT_KERNEL,
-        BT_PARK, BT_SCRATCH_CAP, BT_WGS_PER_CU, BT_RING_SLOTS -> set_tuning().  The library itself never reads the environment."""
+        """Developer convenience for tools/ and tests/: BT_SLICES, BT_QUEUE, BT_PHASE_VOTE, BT_SCRATCH_CAP, BT_WGS_PER_CU ->
+        set_tuning().  The library itself never reads the environment."""
         env = os.environ if environ is None else environ
-        names = {"BT_SLICES": "slices", "BT_TILES_PER_WG": "tiles_per_wg", "BT_QUEUE": "queue",
-                 "BT_PHASE_VOTE": "phase_vote", "BT_PARK": "park", "BT_SCRATCH_CAP": "scratch_cap_bytes",
-                 "BT_WGS_PER_CU": "workgroups_per_cu", "BT_RING_SLOTS": "ring_slots"}
+        names = {"BT_SLICES": "slices", "BT_QUEUE": "queue", "BT_PHASE_VOTE": "phase_vote", "BT_SCRATCH_CAP": "scratch_cap_bytes",
+                 "BT_WGS_PER_CU": "workgroups_per_cu"}
         knobs = {f: int(env[e]) for e, f in names.items() if env.get(e) not in (None, "", "-")}
-        if env.get("BT_KERNEL") in self.KERNEL_VARIANTS:
-            knobs["kernel_variant"] = env["BT_KERNEL"]
         if knobs:
             self.set_tuning(**knobs)
         return knobs

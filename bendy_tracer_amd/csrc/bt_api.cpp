@@ -18,9 +18,6 @@
 #pragma STDC FP_CONTRACT OFF
 
 extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes, hipStream_t stream);
-extern "C" hipError_t bt_launch_render_sorted(const BtLaunch *P, int output, unsigned grid, size_t scene_lds_bytes,
-                                              hipStream_t stream);
-extern "C" size_t bt_sorted_state_bytes(int output);
 extern "C" hipError_t bt_launch_unshard(const float *gathered, float *frame, uint32_t width, uint32_t height,
                                         uint32_t tiles_x, uint32_t tiles_y, uint32_t world, uint32_t tiles_per_rank,
                                         hipStream_t stream);
@@ -35,6 +32,9 @@ thread_local std::string g_error;
 thread_local int g_error_code = 0;
 constexpr uint64_t kDefaultScratchCap = 2ull << 30;   // parked sample values per launch; deeper renders are split
 constexpr uint32_t kScratchShrinkAfter = 8;           // renders in a row that need < 1/4 of the scratch before it shrinks
+constexpr uint64_t kFlowMaxParkedBytes = 128ull << 20; // launches that park at most this much run the flow queue (+ its sum kernel)
+constexpr uint32_t kFlowBlockItems = 512;             // work items of a flow-queue pixel block (>= 256: the kernel's cursor logic)
+constexpr uint32_t kFlowWorkgroupsPerCu = 7;          // persistent workgroups per CU = what __launch_bounds__(256, 7) keeps resident
 int set_error(int code, const std::string &msg) {
     g_error = msg;
     g_error_code = code;
@@ -373,21 +373,19 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     const uint32_t grid = sharded ? (n_tiles + world - 1) / world : n_tiles;
 
-    // Shape of the launch.  More than one ray per pixel -> the work-queue kernel: a workgroup owns a
-    // block of 256 / S pixels and deals their samples to its lanes, every sample's value is parked in `scratch`
-    // (16 B per sample of the launch).  S is chosen so that a workgroup holds ~16 samples per lane (4 with the lens on,
-    // whose paths differ far more in length; down to 4 as well when the launch has too few pixels to fill the GPU).
-    // A render whose scratch would exceed the cap is issued as several launches over consecutive sample ranges
-    // (k launches of m samples == one launch of k * m samples).  One ray per pixel, or no memory for the scratch ->
-    // the lanes kernel, which needs none.  bt_tuning (bt_scene_set_tuning) pins any of these for tests and A/B tools.
+    // Shape of the launch.  A workgroup owns a block of 256 / S pixels and deals their samples to its lanes,
+    // every sample's value is parked in `scratch` (12 B per sample of the launch).  S is chosen so that a workgroup holds
+    // ~16 samples per lane (4 with the lens on, whose paths differ far more in length; down to 4 as well when the launch has
+    // too few pixels to fill the GPU).  A render whose scratch would exceed the cap is issued as several launches over
+    // consecutive sample ranges (k launches of m samples == one launch of k * m samples).  bt_tuning
+    // (bt_scene_set_tuning) pins any of these for tests and A/B tools.
     const bt_tuning &tune = s->tuning;
     const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
     const uint64_t px_launch = (uint64_t)grid * BT_TILE_DIM * BT_TILE_DIM;
     uint32_t chunk = (uint32_t)P.samples;                         // samples per launch
     P.slices = 1;
-    P.tiles_per_wg = 1;
     P.scratch = nullptr;
-    P.stream = 0;
+    P.flow = 0;
     P.table_lds_bytes = (uint32_t)s->flat.lds_bytes();
     size_t lds_bytes = s->flat.lds_bytes();
     {
@@ -430,116 +428,59 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         return true;
     };
     const uint64_t T_all = (uint64_t)P.samples * nn;
-    // 0 = a lane owns a pixel, 1 = block queue (the default whenever a pixel gets more than one ray), 2 = streaming queue
-    // (opt-in through bt_tuning.queue -- no multi-GB scratch, no drain at the end of a block, 65 x less HBM
-    // traffic with its ring in LDS, but 25 % slower on C3 as measured in round 2, profiles/r02e)
-    int qmode = 1;      // also for one ray per pixel: a lane that takes the next pixel when its path ends beats a lane that
-                        // owns one pixel by 1.4 ... 2.9 x (profiles/r02z/time_t1.log: scene.json 1080p 0.44 -> 0.15 ms per call)
-    if (tune.queue >= 0) qmode = tune.queue == 2 && P.lens_on ? 1 : tune.queue;
-    if (qmode == 2 && T_all * (uint64_t)BT_TILE_DIM * BT_TILE_DIM * grid >= (1ull << 40)) qmode = 1;   // item counters are 32 bit per workgroup
-    uint64_t parked_bytes = 0;
-    if (qmode == 2) {
-        // ---- streaming queue: persistent workgroups, a ring of parked units per workgroup ----
-        const uint32_t occ = 6u;           // workgroups per CU: every instantiation fits six (80 VGPRs, <= 112 SGPRs); a seventh that does not
-                                           // become resident would start only when a persistent workgroup ends
-        const uint32_t G_full = (uint32_t)s->n_cu * (tune.workgroups_per_cu ? tune.workgroups_per_cu : occ);
-        // pixel blocks: 64 pixels; smaller when the launch would otherwise have fewer than ~8 blocks per workgroup (the
-        // blocks are claimed dynamically, the last one a workgroup takes is its tail) -- but a block stays >= 1024 items
-        // (4 per lane), so that claiming one (a global atomic, microseconds) stays rare next to working one off
-        uint32_t S = 4;
-        while (S < 32 && (uint64_t)grid * S < 8ull * G_full && (uint64_t)(256u / (2 * S)) * T_all >= 1024) S *= 2;
-        if (tune.slices >= 4) S = tune.slices;
-        const uint32_t pxb = 256u / S;
-        const uint32_t T = (uint32_t)T_all;
-        // ring: four slots; in LDS when a unit of >= 64 items and >= ~6 items per lane in flight fit beside the tables
-        const uint32_t R = tune.ring_slots ? tune.ring_slots : 4;
-        const int64_t lds_budget = (int64_t)(160 * 1024 - 2048) / (tune.workgroups_per_cu ? tune.workgroups_per_cu : occ) - (int64_t)lds_bytes - 3 * 64 * 4 - 64;   // lds_bytes: tables + volume boxes
-        const uint32_t tc_lds = lds_budget > 0 ? (uint32_t)(lds_budget / (int64_t)(R * pxb * 12)) : 0u;
-        bool ring_lds = tc_lds * pxb >= 256 && tc_lds >= 1;
-        if (tune.park >= 0) ring_lds = tune.park == 1 && tc_lds >= 1 && tc_lds * pxb >= 64;
-        uint32_t tc_max = ring_lds ? tc_lds : std::max(1u, 1024u / pxb);       // HBM ring: units of <= 1024 items
-        if (tc_max * pxb < 64) tc_max = 64 / pxb;
-        const uint32_t n_chunks = (T + tc_max - 1) / tc_max;
-        const uint32_t chunk_T = (T + n_chunks - 1) / n_chunks;                  // balanced chunks
-        // a unit must hold >= 64 items (a wave's 64 items span at most two units): the last chunk too
-        const uint32_t last_T = T - chunk_T * (n_chunks - 1);
-        if (last_T * pxb < 64 && n_chunks > 1) {
-            qmode = 1;                                                           // odd sample count that does not cut evenly: block queue
-        } else if (T * pxb < 64) {
-            qmode = 1;
-        } else {
-            P.stream = 1;
-            P.slices = (int32_t)S;
-            P.ring_slots = (int32_t)R;
-            P.ring_lds = ring_lds ? 1 : 0;
-            P.chunk_T = (int32_t)chunk_T;
-            P.n_chunks = (int32_t)n_chunks;
-            P.n_blocks = grid * S;
-            P.unit_cap = pxb * chunk_T;
-            P.stream_grid = std::min<uint32_t>(P.n_blocks, G_full);
-            P.block_counter = (uint32_t *)(s->d_counters + BT_BLOCK_COUNTER_SLOT);
-
-            lds_bytes += 3 * 64 * 4 + (ring_lds ? (size_t)R * P.unit_cap * 12 : 0);
-            const uint64_t need = ring_lds ? 0 : (uint64_t)P.stream_grid * R * P.unit_cap * 3 * sizeof(float);
-            if (!ensure_scratch(need)) return set_error(BT_ERR_DEVICE, "no device memory for the parked samples");
-            P.scratch = s->d_scratch;                                            // null with the ring in LDS
-            parked_bytes = ring_lds ? 0 : px_launch * T_all * 3 * sizeof(float);
-        }
+    const uint64_t per_sample = px_launch * nn * 3 * sizeof(float);          // 12 B per parked sample value
+    const uint64_t cap = tune.scratch_cap_bytes ? tune.scratch_cap_bytes : kDefaultScratchCap;
+    if (per_sample * chunk > cap) chunk = (uint32_t)std::max<uint64_t>(1, cap / per_sample);
+    // the parked values need device memory; when it cannot be had, render fewer samples per launch (there is no path that
+    // does without: a lane that owned a pixel and summed in a register lost every measurement and left in round 3)
+    while (!ensure_scratch(per_sample * chunk)) {
+        if (chunk == 1) return set_error(BT_ERR_DEVICE, "no device memory for the parked samples (" + std::to_string(per_sample) + " bytes per sample)");
+        chunk = (chunk + 1) / 2;
     }
-    if (qmode != 2 || !P.stream) {
-        // ---- block queue or one lane per pixel ----
-        // More than one ray per pixel -> a workgroup owns a block of 256 / S pixels and deals their samples to its lanes,
-        // every sample's value is parked in `scratch` (16 B per sample of the launch).  S is chosen so that a workgroup
-        // holds ~16 samples per lane (4 with the lens on, whose paths differ far more in length; down to 4 as well when
-        // the launch has too few pixels to fill the GPU).  A render whose scratch would exceed the cap is issued as several
-        // launches over consecutive sample ranges (k launches of m samples == one launch of k * m samples).  One ray per
-        // pixel, or no memory for the scratch -> the lanes kernel, which needs none.
-        const uint64_t cap = tune.scratch_cap_bytes ? tune.scratch_cap_bytes : kDefaultScratchCap;
-        auto pick = [&](uint64_t T) -> uint32_t {
-            if (tune.slices) return tune.slices;
-            if (tune.tiles_per_wg > 1) return 1;                  // several whole tiles per workgroup: no cut inside a tile
-            uint32_t S = 1;
-            if (P.lens_on) {
-                while (S < 32 && T / (2 * S) >= 4) S *= 2;       // lens paths differ far more in length: ~4 samples per lane
-            } else {
-                // Measured on 1080p and 512 x 512 frames, T = 1 ... 128 rays per pixel per launch, and on the shards of 2 / 4 / 8
-                // ranks with 128 / 256 / 512 rays (profiles/r02z/time_shallow_before.log, time_shallow_512_before.log, time_shard.log).
-                // A launch wants ~21 rounds of workgroups over the GPU (tiles x S ~ 32 000 on 256 CUs: S = 4 for a full 1080p
-                // frame, 8 / 16 / 32 for the shards) with >= 8 samples per lane; below half of that, 4 samples per lane are
-                // enough; and a frame that cannot even fill the wave slots twice is cut down to one sample per lane.
-                const uint64_t target = 21ull * (uint64_t)s->n_cu * 6;
-                while (S < 32 && (uint64_t)grid * (2 * S) * 4 <= 5 * target && T / (2 * S) >= 8) S *= 2;
-                while (S < 32 && (uint64_t)grid * S * 2 < target && T / (2 * S) >= 4) S *= 2;
-                while (S < 32 && (uint64_t)grid * 4 * S < 2 * wave_slots && T / (2 * S) >= 1) S *= 2;
-            }
-            return S;
-        };
-        bool queue = qmode != 0;
-        if (queue) {
-            // 12 B per parked sample value.  A workgroup that owns tiles_per_wg = 2 or 4 whole tiles parks at
-            // workgroup * (256 * tiles_per_wg * T) + item: the last workgroup's slots exist even when the launch's tile count
-            // is not a multiple of tiles_per_wg, so the scratch is sized for the tile count rounded up to a multiple of 4
-            const uint64_t px_parked = (((uint64_t)grid + 3) / 4 * 4) * BT_TILE_DIM * BT_TILE_DIM;
-            const uint64_t per_sample = px_parked * nn * 3 * sizeof(float);
-            if (per_sample * chunk > cap) chunk = (uint32_t)std::max<uint64_t>(1, cap / per_sample);
-            if (!ensure_scratch(per_sample * chunk)) queue = false;
-        }
-        if (queue) {
-            P.slices = (int32_t)pick((uint64_t)chunk * nn);
-            P.scratch = s->d_scratch;
-            // whole tiles, two or four per workgroup (bt_tuning.tiles_per_wg): round 1 chose two for the interactive pattern
-            // on sphere scenes; with round 2's cheaper samples one tile per workgroup is faster at every depth
-            // (profiles/r02z/time_shallow_before.log: scene.json T = 4: 0.35 vs 0.43 ms), so the automatic choice is 1 -- except for one
-            // ray per pixel, where two tiles (two items per lane) win on all three scene classes (time_t1.log)
-            // one ray per pixel: 512 items per workgroup where the frame has tiles enough for four rounds of those
-            uint32_t tpw = (uint64_t)chunk * nn == 1 && P.slices == 1 && (uint64_t)grid >= 4ull * s->n_cu * 6 ? 2 : 1;
-            if (tune.tiles_per_wg && P.slices == 1) tpw = tune.tiles_per_wg;
-            P.tiles_per_wg = (int32_t)tpw;
-            parked_bytes = px_launch * T_all * 3 * sizeof(float);
+    P.scratch = s->d_scratch;
+    // Flow queue: shallow launches of Output::Full without the lens.  A block queue workgroup ends with a
+    // drain -- lanes that find the queue empty wait for the workgroup's slowest path -- which costs little at 16 samples per
+    // lane and a quarter of the lane slots at 4; persistent workgroups that claim block after block drain once per launch.
+    // What it costs is a second kernel for the ordered sums, which re-reads the parked values: worth it while those are few.
+    int queue = tune.queue >= 1 ? tune.queue : 1;      // measured (profiles/r04b): the flow queue loses on shallow launches, ties on C2
+    if (output != 0 || P.lens_on) queue = 1;
+    auto pick = [&](uint64_t T) -> uint32_t {
+        if (tune.slices) return tune.slices;
+        uint32_t S = 1;
+        if (queue == 2) {
+            while (S < 32 && 256 * T / (2 * S) >= kFlowBlockItems) S *= 2;    // blocks of ~kFlowBlockItems work items, at least 256
+        } else if (P.lens_on) {
+            while (S < 32 && T / (2 * S) >= 4) S *= 2;       // lens paths differ far more in length: ~4 samples per lane
         } else {
-            chunk = (uint32_t)P.samples;
+            // Measured on 1080p and 512 x 512 frames, T = 1 ... 128 rays per pixel per launch, and on the shards of 2 / 4 / 8
+            // ranks with 128 / 256 / 512 rays (profiles/r02z/time_shallow_before.log, time_shallow_512_before.log, time_shard.log).
+            // A launch wants ~21 rounds of workgroups over the GPU (tiles x S ~ 32 000 on 256 CUs: S = 4 for a full 1080p
+            // frame, 8 / 16 / 32 for the shards) with >= 8 samples per lane; below half of that, 4 samples per lane are
+            // enough; and a frame that cannot even fill the wave slots twice is cut down to one sample per lane.
+            const uint64_t target = 21ull * (uint64_t)s->n_cu * 6;
+            while (S < 32 && (uint64_t)grid * (2 * S) * 4 <= 5 * target && T / (2 * S) >= 8) S *= 2;
+            while (S < 32 && (uint64_t)grid * S * 2 < target && T / (2 * S) >= 4) S *= 2;
+            while (S < 32 && (uint64_t)grid * 4 * S < 2 * wave_slots && T / (2 * S) >= 1) S *= 2;
         }
+        return S;
+    };
+    P.slices = (int32_t)pick((uint64_t)chunk * nn);
+    {
+        // a workgroup counts its path segments in 32 bits (bt_stats.segments): keep its work items x the longest possible path
+        // below 2^32 -- only a pinned launch shape (bt_tuning.slices with an enormous scratch cap) can get near
+        const uint64_t longest = ((uint64_t)P.max_bounces + 2) * ((uint64_t)P.max_volume_bounces + 3) + (P.lens_on ? 2 : 0);
+        const uint64_t items_max = std::max<uint64_t>(1, 0xffffffffull / longest);
+        const uint64_t pxb = 256u / (uint32_t)P.slices;
+        if (queue != 2 && pxb * chunk * nn > items_max) chunk = (uint32_t)std::max<uint64_t>(1, items_max / (pxb * nn));
     }
+    P.n_blocks = grid * (uint32_t)P.slices;
+    if (queue == 2) {
+        const uint32_t wpc = tune.workgroups_per_cu ? tune.workgroups_per_cu : kFlowWorkgroupsPerCu;
+        P.flow = 1;
+        P.flow_grid = std::min<uint32_t>(P.n_blocks, (uint32_t)s->n_cu * wpc);
+        P.block_counter = (uint32_t *)(s->d_counters + BT_BLOCK_COUNTER_SLOT);
+    }
+    const uint64_t parked_bytes = px_launch * T_all * 3 * sizeof(float);
 
 #ifdef BT_LDS_PAD                                   // developer build: unused LDS per workgroup, to time lower occupancies
     lds_bytes += BT_LDS_PAD;
@@ -553,27 +494,12 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     uint32_t launches = 0;
     BT_HIP(hipMemsetAsync(s->d_counters, 0, 15 * sizeof(unsigned long long), stream));
     BT_HIP(hipEventRecord(s->ev_start, stream));
-    // Two bit-identical kernels: the regrouping one (bt_kernels_sorted.hip, path state in LDS, lanes
-    // re-sorted by event kind every iteration) and the lane-owns-pixel one (bt_kernels.hip).  The
-    // sorted kernel packs bounce counters into 8 bits and needs ~25 KB of LDS per workgroup on top
-    // of the scene tables; bt_tuning.kernel_variant selects it per handle (A/B runs).
-    const int variant = tune.kernel_variant;
-    const bool can_sort = P.max_bounces < 250 && P.max_volume_bounces < 250 &&
-                          s->flat.lds_bytes() + bt_sorted_state_bytes(output) <= 64 * 1024;
-    const bool use_sorted = can_sort && variant == BT_KERNEL_SORTED && !P.lens_on;   // the lens lives in the lanes kernel
-    if (use_sorted) {                             // the regrouping kernel owns whole pixels
-        P.slices = 1;
-        P.scratch = nullptr;
-        P.stream = 0;
-        parked_bytes = 0;
-        BT_HIP(bt_launch_render_sorted(&P, output, grid, s->flat.lds_bytes(), stream));
-        launches = 1;
-    } else {
+    {
         const uint32_t all = (uint32_t)P.samples, base = P.sample_base;
         for (uint32_t done = 0; done < all; done += chunk) {
             P.samples = (int32_t)std::min(chunk, all - done);
             P.sample_base = base + done;
-            if (P.stream) BT_HIP(hipMemsetAsync(P.block_counter, 0, sizeof(unsigned long long), stream));
+            if (P.flow) BT_HIP(hipMemsetAsync(P.block_counter, 0, sizeof(unsigned long long), stream));
             BT_HIP(bt_launch_render(&P, output, grid, lds_bytes, stream));
             launches += 1;
         }
@@ -595,6 +521,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     s->last.segments = 0;
     s->last.kernel_ms = 0.0f;
     s->last.slices = (uint32_t)P.slices;
+    s->last.queue = P.flow ? 2u : 1u;
     s->last.launches = launches;
     s->last.scratch_bytes = s->scratch_bytes;
     s->last.parked_bytes = parked_bytes;
@@ -633,7 +560,6 @@ void bt_tuning_default(bt_tuning *t) {
     std::memset(t, 0, sizeof *t);
     t->queue = -1;
     t->phase_vote = -1;
-    t->park = -1;
 }
 
 int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
@@ -642,17 +568,13 @@ int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
         bt_tuning_default(&scene->tuning);
         return 0;
     }
-    const uint32_t S = t->slices, W = t->tiles_per_wg;
+    const uint32_t S = t->slices;
     if (!(S == 0 || S == 1 || S == 2 || S == 4 || S == 8 || S == 16 || S == 32))
         return set_error(BT_ERR_INVALID_ARG, "bt_tuning.slices must be 0 (auto), 1, 2, 4, 8, 16 or 32");
-    if (!(W == 0 || W == 1 || W == 2 || W == 4))
-        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.tiles_per_wg must be 0 (auto), 1, 2 or 4");
-    if (t->kernel_variant != BT_KERNEL_DEFAULT && t->kernel_variant != BT_KERNEL_LANES && t->kernel_variant != BT_KERNEL_SORTED)
-        return set_error(BT_ERR_INVALID_ARG, "unknown kernel variant");
-    if (t->workgroups_per_cu > 8 || !(t->ring_slots == 0 || t->ring_slots == 2 || t->ring_slots == 4))
-        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.workgroups_per_cu must be 0 .. 8, ring_slots 0, 2 or 4");
-    if (t->queue < -1 || t->queue > 2 || t->park < -1 || t->park > 1 || t->phase_vote < -1 || t->phase_vote > 64)
-        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.queue must be -1 .. 2, park -1, 0 or 1, phase_vote -1 .. 64");
+    if (t->workgroups_per_cu > 8)
+        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.workgroups_per_cu must be 0 .. 8");
+    if (!(t->queue == -1 || t->queue == 1 || t->queue == 2) || t->phase_vote < -1 || t->phase_vote > 64)
+        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.queue must be -1 (auto), 1 (block queue) or 2 (flow queue), phase_vote -1 .. 64");
     scene->tuning = *t;
     return 0;
 }
@@ -900,23 +822,6 @@ int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {
         BT_HIP(hipEventSynchronize(scene->ev_stop));
         unsigned long long c[16] = {0, 0};
         BT_HIP(hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
-#ifdef BT_STREAM_DEBUG                              // developer build of the whole library (FLAGS += -DBT_STREAM_DEBUG)
-        fprintf(stderr, "[bt stream] lane-iterations %llu, waiting for a ring slot %llu, claim-lock spins %llu; watchdog: slot wait %#llx %#llx, claim %#llx\n", c[3], c[4], c[5], c[6], c[7], c[8]);
-#endif
-#ifdef BT_XCCSTAT
-        // developer build (-DBT_XCCSTAT): when each XCD's last wave ended, in microseconds after the first wave's start
-        {
-            const unsigned long long t0 = ~c[10];
-            fprintf(stderr, "[bt xcc] last wave of XCD 0..7 ended at (us):");
-#if BT_XCCSTAT == 2
-            for (int i = 0; i < 8; ++i) fprintf(stderr, " [%llu workgroups]", c[2 + i]);
-            (void)t0;
-#else
-            for (int i = 0; i < 8; ++i) fprintf(stderr, " %.1f", c[2 + i] ? (double)(c[2 + i] - t0) / 100.0 : 0.0);
-#endif
-            fprintf(stderr, "\n");
-        }
-#endif
 #ifdef BT_LANESTAT
         // developer build (-DBT_LANESTAT): what the lanes of a wave do per iteration, see bt_kernels.hip
         if (c[2]) {

@@ -359,20 +359,15 @@ BT_DEV void intersect_row(BtPrimK *prims, int i, V3 o, V3 d, float tmin, int las
 // float2 lanes (v_pk_add_f32 / v_pk_mul_f32, the pair's constants straight from SGPR pairs) -- the same IEEE
 // operations in the same order per sphere as sphere_t() -- then each sphere's root selection runs against the running
 // clip, first sphere first, exactly as the one-at-a-time loop does.
-#ifndef BT_PK_PAIRS
-#define BT_PK_PAIRS 0          // 1: the two-sphere / two-row arithmetic in v_pk_* instructions (round 1; slower since the kernels are register-bound: profiles/r03c/ab_nopk.log)
-#endif
-#if BT_PK_PAIRS
-typedef float f2 __attribute__((ext_vector_type(2)));
-BT_DEV f2 splat2(float v) { return (f2)(v); }
-#else
+// (round 1 formed the pair in float2 lanes, v_pk_add_f32 / v_pk_mul_f32; a packed instruction occupies the issue port as
+// long as the two scalar ones and needs aligned register pairs: slower since the kernels are register-bound,
+// profiles/r03c/ab_nopk.log)
 struct f2 { float x, y; };
 BT_DEV f2 splat2(float v) { return f2{v, v}; }
 BT_DEV f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
 BT_DEV f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
 BT_DEV f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
 BT_DEV f2 operator*(f2 a, float b) { return f2{a.x * b, a.y * b}; }
-#endif
 template <bool VOLS>
 BT_DEV HitRec intersect_spheres(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax, int last_object) {
     HitRec h;
@@ -697,26 +692,6 @@ BT_DEV float density_sample(const BtVolume &vol, const float *density, V3 coord)
     return lerpf(z0, z1, tz);
 }
 
-// Pixel q of block `sub` of a 16x16 tile that is cut into 256 / pxb blocks (bt_render_kernel's mapping): blocks of
-// 256, 128 or 64 pixels are made of whole 8x8 quadrants, smaller ones are 8x4 (pxb 32), 4x4 (pxb 16) or 4x2 (pxb 8) pixels,
-// numbered row-major inside the tile.
-struct BlockPixel { uint32_t x, y; };
-BT_DEV BlockPixel block_pixel(uint32_t sub, uint32_t q, uint32_t pxb) {
-    BlockPixel r;
-    if (pxb >= 64) {
-        const uint32_t quad = (sub * pxb + q) >> 6;
-        r.x = ((quad & 1) << 3) | (q & 7);
-        r.y = ((quad >> 1) << 3) | ((q & 63) >> 3);
-    } else {
-        // 8x4, 4x4, 4x2: every size is a power of two -- shifts and masks (a `%` by a value the compiler cannot see is a
-        // twenty-instruction division, and this runs once per work item)
-        const uint32_t lbw = pxb >= 32 ? 3u : 2u, lbh = (uint32_t)__builtin_ctz(pxb) - lbw, lnbx = 4u - lbw;
-        r.x = ((sub & ((1u << lnbx) - 1u)) << lbw) + (q & ((1u << lbw) - 1u));
-        r.y = ((sub >> lnbx) << lbh) + (q >> lbw);
-    }
-    return r;
-}
-
 // DensityMap::sample for maps whose bounds tests cannot fire (BtLaunch::vols_safe): density_sample() without the clamp of
 // negative indices and the width / height / depth tests of density_at() -- cx = clamp(coord, 0, 1) * size lies in
 // [0, size] (NaN clamps to 0), so floor and ceil lie in [0, dim - 1].  Same fetches, same lerps, same bits.
@@ -778,6 +753,10 @@ BT_DEV float march_density(const BtLaunch &P, const SceneLds &S, int vol_index, 
     const V3 coord = mk(rel.x / size.x, rel.y / size.y, rel.z / size.z);
     return P.volume_step * density_sample(vol, S.density, coord);
 }
+
+// lanes set in a wave64 mask, as two 32-bit scalar popcounts: comparisons of the result stay on the scalar unit (the 64-bit
+// popcount's result is compared with a 64-bit VALU compare)
+BT_DEV uint32_t popc64(unsigned long long m) { return (uint32_t)__builtin_popcount((uint32_t)m) + (uint32_t)__builtin_popcount((uint32_t)(m >> 32)); }
 
 BT_DEV unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll

@@ -9,11 +9,14 @@
 //   march (volume.rs) -> `+=` into the RGBA32F accumulator (buffer.rs:159-178).
 //
 // Mapping to the hardware:
-//   * a workgroup owns a block of 256/S pixels (S = 1..32; or 2 / 4 whole tiles for very shallow launches) and all
-//     of their samples in this launch.  Whenever a pixel gets more than one ray the block's (pixel, sample) pairs are
-//     a work queue in LDS: a lane whose path has ended takes the next pair, every sample's value is parked in HBM and
-//     the last wave of the workgroup adds the parked values to the frame in sample order -- the reference's per-pixel
-//     summation order, no atomics on the frame.  With one ray per pixel a lane owns one pixel and sums in a register;
+//   * a workgroup owns a block of 256/S pixels (S = 1..32; or 2 / 4 whole tiles for very shallow launches) and all of
+//     their samples in this launch.  The block's (pixel, sample) pairs are a work queue in LDS: a lane whose path has
+//     ended takes the next pair, every sample's value is parked in HBM and the last wave of the workgroup adds the
+//     parked values to the frame in sample order -- the reference's per-pixel summation order, no atomics on the frame;
+//   * flow queue (shallow launches, BtLaunch::flow): the launch is a few persistent workgroups per CU that CLAIM pixel
+//     blocks from a counter in HBM and deal each block's pairs the same way, but a lane flows on into the workgroup's
+//     next block instead of waiting for the block's slowest path; the ordered sums are a second, tiny kernel
+//     (bt_sum_parked_kernel) over the parked values;
 //   * in the sphere-only builds a wave votes every iteration whether it runs the camera event or the scatter / volume
 //     events; the lanes of the other kind keep their state for the next iteration (phase voting);
 //   * every loop iteration is TRACE (one path segment, all lanes) followed by exactly ONE random event per lane --
@@ -26,6 +29,10 @@
 //     staged in LDS; the camera block of the launch parameters is read where it is used, not kept in SGPRs;
 //   * template flags select a build without rect code / without the volume march for scenes that have neither;
 //   * no MFMA: there is no dense contraction on this path.
+//
+// Round 3 removed what had lost every measurement of rounds 1 and 2 (the logs stay under profiles/): the lane-owns-pixel
+// mapping, the streaming queue with its ring of parked units, the regrouping kernel (bt_kernels_sorted.hip) and the A/B
+// knobs BT_VOTE3, BT_VOTE_SOFT_K, BT_XCD_ROTATE, BT_PK_PAIRS, BT_WG_THREADS, BT_VOTE_RECTS, BT_NUM_SGPR, BT_WAVES_EXACT.
 #include "bt_device.hpp"
 
 // Developer build (-DBT_PROFILE): s_memtime stamps around the sections of the render loop, summed per wave into
@@ -53,101 +60,180 @@ struct Parked { float x, y, z; };
 
 enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 };
 
+// lanes of a wave64 mask below this lane
+BT_DEV uint32_t lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// the lanes that execute THIS instruction: EXEC read in place (a `__ballot(true)` is an expression the optimizer may
+// evaluate earlier, where lanes that have since left for the loop head still count)
+BT_DEV unsigned long long exec_here() {
+    unsigned long long m;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(m));
+    return m;
+}
+
+// ---- where a pixel block lies in the frame ---------------------------------------------------------------------------
+// BtLaunch::slices = NS in {1,2,4,8,16,32}: a 16x16 tile is cut into NS blocks of pxb = 256/NS pixels -- whole 8x8 quadrants
+// down to 64 pixels, then 8x4, 4x4, 4x2 pixels, numbered row-major inside the tile.  Block b of the launch is block
+// b mod NS of the launch's tile b / NS.  The tile (a division by tiles_x: umulhi + one fix-up step) and the block's corner
+// inside it depend on the block alone: computed once per block (wave-uniform: scalar), not once per work item.
+struct BlockGeom { uint32_t NS, LOG_NS, pxb, LOG_PXB, LBW, WMASK; };
+BT_DEV BlockGeom block_geom(const BtLaunch &P) {
+    BlockGeom g;
+    g.NS = (uint32_t)P.slices;
+    g.LOG_NS = (uint32_t)__builtin_ctz(g.NS);
+    g.pxb = 256u >> g.LOG_NS;                          // pixels per block
+    g.LOG_PXB = 8u - g.LOG_NS;
+    g.LBW = g.pxb >= 32 ? 3u : 2u;                     // log2 of a block row: whole quadrants and 8x4 blocks are 8 pixels wide
+    g.WMASK = (1u << g.LBW) - 1u;
+    return g;
+}
+struct BlockRef { uint32_t px0, py0, tile_ok, slot; };
+BT_DEV BlockRef block_ref(const BtLaunch &P, const BlockGeom &g, uint32_t b) {      // b: block in launch order
+    const uint32_t slot = b >> g.LOG_NS, sub = b & (g.NS - 1u);
+    const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
+    uint32_t ty = __umulhi(tile, P.tiles_x_magic), tx = tile - ty * P.tiles_x;      // tile / tiles_x, exact after the fix-up
+    if (tx >= P.tiles_x) { ty += 1u; tx -= P.tiles_x; }
+    // corner of block `sub` inside the tile: 128 pixels = the quadrant row `sub`, 64 = quadrant `sub`, below that blocks
+    // of 8x4 / 4x4 / 4x2 pixels numbered row-major
+    uint32_t bx0 = 0, by0 = 0;
+    if (g.pxb == 128) by0 = sub << 3;
+    else if (g.pxb == 64) { bx0 = (sub & 1u) << 3; by0 = (sub >> 1) << 3; }
+    else if (g.pxb < 64) {
+        const uint32_t lbh = g.LOG_PXB - g.LBW, lnbx = 4u - g.LBW;
+        bx0 = (sub & ((1u << lnbx) - 1u)) << g.LBW;
+        by0 = (sub >> lnbx) << lbh;
+    }
+    BlockRef r;
+    r.px0 = tx * BT_TILE_DIM + bx0;
+    r.py0 = ty * BT_TILE_DIM + by0;
+    r.tile_ok = ty < P.tiles_y ? 1u : 0u;
+    r.slot = slot;
+    return r;
+}
+// pixel q of a block: quadrants 1 .. 3 of a 128- or 256-pixel block sit to the right of / below quadrant 0
+struct PixelRef { uint32_t px, py; bool in_frame; };
+BT_DEV PixelRef pixel_of(const BtLaunch &P, const BlockGeom &g, const BlockRef &B, uint32_t q) {
+    PixelRef r;
+    r.px = B.px0 + (q & g.WMASK) + ((q >> 3) & 8u);
+    r.py = B.py0 + ((q & 63u) >> g.LBW) + ((q >> 4) & 8u);
+    r.in_frame = B.tile_ok && r.px < P.width && r.py < P.height;
+    return r;
+}
+// the pixel's running sum: row-major frame, or this rank's tile-major shard
+BT_DEV float *out_of(const BtLaunch &P, const BlockRef &B, const PixelRef &r) {
+    return P.sharded ? P.out + ((size_t)B.slot * (BT_TILE_DIM * BT_TILE_DIM) + (r.py & 15u) * BT_TILE_DIM + (r.px & 15u)) * 4
+                     : P.out + ((size_t)r.py * P.width + r.px) * 4;
+}
+
+// `*r += pixel.r` (buffer.rs:159-164) for every parked sample of block b's pixels, in sample order -- the additions a
+// lane that owned the pixel would perform in a register, in the same order, hence the same bits.  Executed by ONE wave
+// (`lane` = 0 .. 63); src = the block's parked values, src[k * pxb + pixel].
+BT_DEV void sum_block(const BtLaunch &P, const BlockGeom &g, uint32_t b, uint32_t T, const Parked *src, uint32_t lane) {
+    const BlockRef B = block_ref(P, g, b);
+    const uint32_t pxb = g.pxb;
+    if (pxb >= 64) {
+        for (uint32_t q = lane; q < pxb; q += 64) {
+            const PixelRef r = pixel_of(P, g, B, q);
+            if (!r.in_frame) continue;
+            float *o = out_of(P, B, r);
+            const Parked *s = src + q;
+            V3 sum = mk(o[0], o[1], o[2]);
+            uint32_t kk = 0;
+            for (; kk + 8 <= T; kk += 8) {             // eight loads in flight, additions strictly in order
+                Parked v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = s[(size_t)(kk + j) * pxb];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
+            }
+            for (; kk < T; ++kk) {
+                const Parked v = s[(size_t)kk * pxb];
+                sum = sum + mk(v.x, v.y, v.z);
+            }
+            o[0] = sum.x;
+            o[1] = sum.y;
+            o[2] = sum.z;
+        }
+    } else {
+        // 32, 16 or 8 pixels (deep launches, T in the hundreds): J = 64 / pxb lanes per pixel fetch interleaved
+        // samples (8 J in flight per pixel), lane (q, 0) adds them in sample order out of the others' registers
+        const uint32_t J = 64u >> g.LOG_PXB, q = lane & (pxb - 1u), jl = lane >> g.LOG_PXB;
+        const PixelRef r = pixel_of(P, g, B, q);
+        const bool owner = jl == 0 && r.in_frame;
+        float *o = out_of(P, B, r);
+        const Parked *s = src + q;
+        V3 sum = mk(0.0f, 0.0f, 0.0f);
+        if (owner) sum = mk(o[0], o[1], o[2]);
+        for (uint32_t kk = 0; kk < T; kk += 8 * J) {
+            Parked v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t k2 = kk + (uint32_t)u * J + jl;
+                v[u] = k2 < T ? s[(size_t)k2 * pxb] : Parked{0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                for (uint32_t jj = 0; jj < J; ++jj) {
+                    const int from = (int)(q + jj * pxb);
+                    const V3 val = mk(__shfl(v[u].x, from, 64), __shfl(v[u].y, from, 64), __shfl(v[u].z, from, 64));
+                    if (kk + (uint32_t)u * J + jj < T) sum = sum + val;
+                }
+        }
+        if (owner) {
+            o[0] = sum.x;
+            o[1] = sum.y;
+            o[2] = sum.z;
+        }
+    }
+}
+
 } // namespace
 
 // --------------------------------------------------------------------------------------------
 // The render kernel.  OUTPUT: 0 Full, 1 Albedo, 2 Normal, 3 Depth (tracer/mod.rs:108-115).
-// Block = 256 threads = one 16x16 pixel tile (BT_TILE); wave w covers the 8x8 quadrant w.
-// 6 waves per SIMD caps the allocation at 80 VGPRs (6 dwords of scratch per lane, outside the hot blocks):
-// measured best once the camera block stopped living in SGPRs (profiles/r01d/ab_w678.log: C3 4.69 / 4.52 / 4.77 /
-// 5.48 ms at 5 / 6 / 7 / 8 waves; Cornell 15.6 / 15.0 / 14.7 / 14.6); round 1b had settled on 5 (96 VGPRs).
+// Block = 256 threads; 7 waves per SIMD caps the allocation at 72 VGPRs (round 2, without the SLP vectorizer;
+// profiles/r03c/ab_waves_noslp.log, ab_waves_per_class.log).
 #ifndef BT_WAVES_PER_SIMD
-#define BT_WAVES_PER_SIMD 7              // VGPR budget 72 (round 2, without the SLP vectorizer; profiles/r03c/ab_waves_noslp.log)
+#define BT_WAVES_PER_SIMD 7
 #endif
 #ifndef BT_WAVES_PER_SIMD_VOLS
 #define BT_WAVES_PER_SIMD_VOLS BT_WAVES_PER_SIMD     // sphere scenes with volumes (own knob for A/B runs)
 #endif
 #ifndef BT_WAVES_PER_SIMD_RECTS
-#define BT_WAVES_PER_SIMD_RECTS 7      // 72 VGPRs: round 1's choice (with 64 B of spills), 6 in the middle of round 2 (spills cost more
-#endif                                 // than the wave hid, profiles/r02l), 7 again without the SLP vectorizer: 73 -> 72 VGPRs, Cornell -1 %
+#define BT_WAVES_PER_SIMD_RECTS 7
+#endif
 #ifndef BT_WAVES_PER_SIMD_LENS
 #define BT_WAVES_PER_SIMD_LENS 6       // lens builds: 80 VGPRs + ~100 B of scratch per lane still beat 4 waves without
 #endif                                 // scratch (665 -> 719 Msamples/s, profiles/r01g/ab_lens_waves.log)
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
 #define BT_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local")   // orders LDS accesses only (lgkmcnt)
-#define BT_RING_MAX 4               // most ring slots of the streaming queue (BtLaunch::ring_slots)
-#ifndef BT_VOTE_SOFT_K
-#define BT_VOTE_SOFT_K 0       // A/B knob, see the phase vote
-#endif
-#ifndef BT_XCD_ROTATE
-#define BT_XCD_ROTATE 0        // A/B knob: rotate each group of eight blocks over the XCDs by (group * BT_XCD_ROTATE) mod 8
-#endif
-#ifndef BT_NO_COUNTERS
-#define BT_NO_COUNTERS 0       // 1: timing experiment without the per-wave atomicAdd of the segment count
-#endif
-#ifndef BT_WG_THREADS
-#define BT_WG_THREADS 256      // lanes per workgroup of the block queue (A/B knob: 64 / 128 / 256)
-#endif
 #ifndef BT_SKIP_DIR
 #define BT_SKIP_DIR 1          // a wave of pass-through march steps skips the direction sampling
-#endif
-#ifndef BT_VOTE3
-#define BT_VOTE3 0                 // 1: builds with volumes vote between three kinds of event (measured slower, profiles/r02d/ab_vote3_rejected.log)
-#endif
-#ifndef BT_VOTE_RECTS
-#define BT_VOTE_RECTS 0            // phase voting in the rect builds too (A/B knob; measured in profiles/r02c)
 #endif
 #ifndef BT_LENS_BATCH
 #define BT_LENS_BATCH 8            // RK4 steps a lane marches per loop iteration before it yields
 #endif
-// SLICED: several waves share a pixel block's samples (BtLaunch::slices); a separate instantiation so that the
-// lane-owns-pixel build keeps its registers and has no global stores inside the loop.
 // RECTS = false: sphere-only scenes (scene.json, volume.json, cloud.json) run a build without any rect / cuboid code.
 // VOLS = false: no sphere carries a volume (scene.json, the Cornell boxes): the march and Volume::shade drop out.
-// QMODE: 0 = a lane owns a pixel; 1 = block queue (SLICED: a workgroup owns one pixel block, parks in HBM scratch); 2 = the
-// streaming queue (STREAM): a persistent workgroup walks its pixel blocks one after the other, see "streaming" below.
-#ifndef BT_NUM_SGPR
-#define BT_NUM_SGPR 0              // > 0: cap the kernels' SGPRs (A/B knob: <= 96 allows a seventh wave per SIMD on gfx950)
-#endif
-#if BT_NUM_SGPR > 0
-#define BT_SGPR_ATTR __attribute__((amdgpu_num_sgpr(BT_NUM_SGPR)))
-#elif defined(BT_WAVES_EXACT)          // A/B knob: min = max waves per SIMD, so that the SGPR budget is that of BT_WAVES_EXACT waves
-#define BT_SGPR_ATTR __attribute__((amdgpu_waves_per_eu(BT_WAVES_EXACT, BT_WAVES_EXACT)))
-#else
-#define BT_SGPR_ATTR
-#endif
-template <int OUTPUT, bool LENS, int QMODE, bool RECTS, bool VOLS>
-__global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : (VOLS ? BT_WAVES_PER_SIMD_VOLS : BT_WAVES_PER_SIMD))) BT_SGPR_ATTR void bt_render_kernel(BtLaunch P) {
-    constexpr bool SLICED = QMODE != 0;    // samples come from a work queue and are parked for the ordered sum
-#ifdef BT_XCCSTAT
-    const unsigned long long xcc_t0 = wall_clock64();
-#endif
-    constexpr bool STREAM = QMODE == 2;
+// FLOW = true: the flow queue (persistent workgroups claim pixel blocks; OUTPUT = Full without the lens only).
+template <int OUTPUT, bool LENS, bool RECTS, bool VOLS, bool FLOW>
+__global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : (VOLS ? BT_WAVES_PER_SIMD_VOLS : BT_WAVES_PER_SIMD))) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_waves_done;      // block queue: waves of this workgroup that have parked all their samples
     __shared__ uint32_t s_next_item;       // the workgroup's work queue (next unclaimed (pixel, sample) pair)
-    __shared__ uint32_t s_segments;        // block queue: path segments traced by this workgroup
-    __shared__ uint32_t s_summed;          // STREAM: units whose samples have been added to the frame (in order)
-    __shared__ uint32_t s_ready;           // STREAM: bit r = the unit in ring slot r is complete and waits for its sum
-    __shared__ uint32_t s_done[BT_RING_MAX]; // STREAM: finished items of the unit in ring slot r
-    __shared__ uint32_t s_blk[16];         // STREAM: the pixel block (launch order) behind this workgroup's n-th block, n mod 16
-    __shared__ uint32_t s_nclaimed;        // STREAM: blocks claimed so far
-    __shared__ uint32_t s_end_local;       // STREAM: this workgroup's first block number past the end of the launch
-    __shared__ uint32_t s_claim_lock;
-    if (SLICED && threadIdx.x == 0) {
+    __shared__ uint32_t s_segments;        // path segments traced by this workgroup
+    __shared__ uint32_t s_blk[4];          // flow queue: the pixel block (launch order) behind this workgroup's n-th block, n mod 4
+    __shared__ uint32_t s_nclaimed;        // flow queue: blocks claimed so far (s_blk[n & 3] is valid for n < s_nclaimed)
+    if (threadIdx.x == 0) {
         s_waves_done = 0;
         s_next_item = 0;
         s_segments = 0;
-        s_summed = 0;
-        s_ready = 0;
-        for (int r = 0; r < BT_RING_MAX; ++r) s_done[r] = 0;
-        if (STREAM) {                       // the first two blocks of this workgroup's walk
+        if (FLOW) {                        // the first two blocks of this workgroup's walk (0xffffffff: the launch has none left)
             const uint32_t b0 = atomicAdd(P.block_counter, 1u), b1 = b0 < P.n_blocks ? atomicAdd(P.block_counter, 1u) : b0;
-            s_blk[0] = b0;
-            s_blk[1] = b1;
-            s_nclaimed = b0 >= P.n_blocks ? 0u : (b1 >= P.n_blocks ? 1u : 2u);
-            s_end_local = b0 >= P.n_blocks ? 0u : (b1 >= P.n_blocks ? 1u : 0xffffffffu);
-            s_claim_lock = 0;
+            s_blk[0] = b0 < P.n_blocks ? b0 : 0xffffffffu;
+            s_blk[1] = b1 < P.n_blocks ? b1 : 0xffffffffu;
+            s_nclaimed = 2;
         }
     }
 
@@ -183,8 +269,6 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         S.density = dens_lds ? dens : P.density;
         __syncthreads();
     }
-    // STREAM: behind the scene tables (BtLaunch::table_lds_bytes) the running sums of the block being summed and, when it
-    // fits, the ring of parked sample values
     BtVolBox *const vbox = (BtVolBox *)(smem + P.table_lds_bytes);      // VOLS builds: bt_types.h BtVolBox, one per primitive
     if (VOLS && P.vbox_lds_bytes) {
         for (int i = threadIdx.x; i < P.n_prims; i += blockDim.x) {
@@ -203,79 +287,29 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         }
         __syncthreads();
     }
-    float *const s_accum = (float *)(smem + P.table_lds_bytes + P.vbox_lds_bytes);
-    float *const ring_l = s_accum + 3 * 64;
 
     // ---- tile / pixel mapping ----
-    // !SLICED: a workgroup is one 16x16 tile, wave w = its 8x8 quadrant w, a lane owns one pixel and walks that
-    // pixel's samples in order (the per-pixel sum lives in `acc`).
-    // SLICED (BtLaunch::slices = NS in {1,2,4,8,16,32}): the tile is cut into NS blocks of pxb = 256/NS pixels and a
-    // workgroup owns one block: its pxb * T (pixel, sample) pairs are work items i = k * pxb + pixel, handed out
-    // through an LDS counter (one atomic per wave and iteration, see the loop) -- a lane whose path has ended takes
-    // the next item, so all 256 lanes stay busy until the block's samples run out, and 64 consecutive items are the
-    // same sample of neighbouring pixels (coherent camera rays).  Every sample's value is parked at
-    // scratch[(block * T + k) * pxb + pixel]; the last wave to finish adds them to the frame in sample order (end of
-    // the kernel).
-    // Shallow launches (T <= 8) go the other way: a workgroup owns TPW = 2 or 4 whole tiles (NS = 1), so that a lane
-    // still gets ~8 items and the drain at the end of a workgroup stays short (BtLaunch::tiles_per_wg).
-    const uint32_t NS = SLICED ? (uint32_t)P.slices : 1u;
-    const uint32_t TPW = SLICED ? (uint32_t)P.tiles_per_wg : 1u;
-    const uint32_t LOG_NS = (uint32_t)__builtin_ctz(NS);
-    const uint32_t pxb = (256u * TPW) >> LOG_NS;       // pixels per block
-#if BT_XCD_ROTATE
-    // workgroups go to the 8 XCDs round robin: rotate the eight blocks of every group by the group's number, so that no
-    // XCD is tied to one column parity / quadrant of the tiles
-    const uint32_t bi = SLICED && !STREAM && blockIdx.x < (gridDim.x & ~7u)
-                            ? (blockIdx.x & ~7u) | ((blockIdx.x + (blockIdx.x >> 3) * BT_XCD_ROTATE) & 7u) : blockIdx.x;
-#else
-    const uint32_t bi = blockIdx.x;                    // block index in launch order
-#endif
+    // A workgroup owns one pixel block of pxb = 256 / slices pixels (block_ref() above): its pxb * T (pixel, sample) pairs are
+    // work items i = k * pxb + pixel, handed out through an LDS counter (one atomic per wave and iteration, see the loop)
+    // -- a lane whose path has ended takes the next item, so all 256 lanes stay busy until the block's samples run out, and
+    // 64 consecutive items are the same sample of neighbouring pixels (coherent camera rays).  Every sample's value is
+    // parked at scratch[block * pxb * T + i]; the last wave to finish adds them to the frame in sample order (end of the
+    // kernel).
+    const BlockGeom G = block_geom(P);
+    const uint32_t pxb = G.pxb, LOG_PXB = G.LOG_PXB;
     const uint32_t lane = threadIdx.x & 63;
-    // pixel q of this workgroup's block: frame coordinates, whether it exists, and where its running sum lives
-    struct PixelRef { uint32_t px, py; bool in_frame; float *out; };
-    auto locate = [&](uint32_t q) -> PixelRef {
-        const uint32_t slot = TPW > 1 ? bi * TPW + (q >> 8) : bi >> LOG_NS;         // tile slot in launch order (NS = 2^LOG_NS)
-        const BlockPixel b = TPW > 1 ? block_pixel(0, q & 255u, 256u) : block_pixel(bi & (NS - 1u), q, pxb);
-        const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
-        uint32_t ty = __umulhi(tile, P.tiles_x_magic), tx = tile - ty * P.tiles_x;      // tile / tiles_x, exact after the fix-up
-        if (tx >= P.tiles_x) { ty += 1u; tx -= P.tiles_x; }
-        PixelRef r;
-        r.px = tx * BT_TILE_DIM + b.x;
-        r.py = ty * BT_TILE_DIM + b.y;
-        r.in_frame = (ty < P.tiles_y) && (r.px < P.width) && (r.py < P.height);
-        r.out = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + b.y * BT_TILE_DIM + b.x) * 4
-                          : P.out + ((size_t)r.py * P.width + r.px) * 4;
-        return r;
-    };
     const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
     const uint32_t T = (uint32_t)P.samples * nn;       // samples per pixel in this launch
     const uint32_t sample0 = P.sample_base * nn;
+    const uint32_t n_items = pxb * T;                  // work items of one block
+    // block queue: this workgroup's one block (launch order = blockIdx.x)
+    const BlockRef B_own = block_ref(P, G, FLOW ? 0u : blockIdx.x);
 
-    // the lane's current pixel and sample: fixed pixel / k = 0, 1, ... when !SLICED, taken from the queue when SLICED
-    uint32_t px, py, pixel_index, k = 0;
-    uint32_t park_i = 0;                               // block queue: the current item's number i = k * pxb + pixel; its value is
-                                                       // parked at scratch[block * T * pxb + i] (32 bits instead of a pointer: one VGPR less)
-    // STREAM: the lane's item -- unit (sequence number in this workgroup's walk), place in the ring, state bits
-    uint32_t my_unit = 0, park_idx = 0, item_flags = 0;    // flags: 1 finished (to be counted), 2 reserved (waits for its ring slot), 4 last chunk
-    const uint32_t ring_items = STREAM ? (uint32_t)P.ring_slots * P.unit_cap : 0u;
-    float *out_px = nullptr;
-    bool alive;
-    V3 acc = mk(0.0f, 0.0f, 0.0f);
-    const uint32_t n_items = SLICED ? pxb * T : 0u;
-    const uint32_t LOG_PXB_ALL = (uint32_t)__builtin_ctz(pxb);
-    if (SLICED) {
-        px = py = pixel_index = 0;
-        alive = true;                                  // until the workgroup's queue is empty (see the loop)
-    } else {
-        const PixelRef r = locate(threadIdx.x);
-        px = r.px;
-        py = r.py;
-        pixel_index = py * P.width + px;
-        out_px = r.out;
-        alive = r.in_frame;
-        if (alive) acc = mk(out_px[0], out_px[1], out_px[2]);            // `*r += pixel.r` (buffer.rs:159-164)
-    }
-    const bool in_frame = alive;                       // !SLICED: this lane's pixel exists
+    // the lane's current work item: pixel_index keys the Philox counter; park_i = the item's number i = k * pxb + pixel in
+    // its block, where its value is parked (block queue: + the workgroup's base; the sample number k comes out of it, one
+    // register less than keeping both -- flow queue: + block * n_items, and k travels in k_cur)
+    uint32_t px = 0, py = 0, pixel_index = 0, park_i = 0, k_cur = 0;
+    bool alive = true;                                 // until the workgroup's queue is empty (see the loop)
 
     // per-lane path state
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, -1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
@@ -286,15 +320,14 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     uint32_t event = 0;
     bool pending = true;               // the lane has no ray yet: its next event is the camera ray
     // phase voting (BtLaunch::phase_vote): a lane whose scatter event lost the vote keeps its hit for the next iteration
-    constexpr bool VOTE = (!RECTS || BT_VOTE_RECTS) && !LENS;    // pays where the events, not TRACE, are most of an iteration
+    constexpr bool VOTE = !RECTS && !LENS;    // pays where the events, not TRACE, are most of an iteration
     bool held = false;
     float held_t = 0.0f;
     int held_info = 0, waited = 0;     // held_info = prim | inside << 29 | p_neg << 30
-    // path segments of this lane (bt_stats::segments).  The block queue counts in 32 bits (a lane sees at most
-    // scratch cap / 12 B / 256 items per launch) and adds up per workgroup in LDS: one device atomic per workgroup, issued
-    // by the wave that sums the block, instead of one 64-bit wave reduction + atomic per wave
-    constexpr bool WG_COUNT = SLICED && !STREAM && !LENS;
-    typename std::conditional<WG_COUNT, uint32_t, unsigned long long>::type segments = 0;
+    // path segments of this lane (bt_stats::segments): counted in 32 bits per lane and added up per workgroup in LDS --
+    // one device atomic per workgroup, issued by the wave that sums the block.  (A lane sees at most
+    // scratch cap / 12 B / 256 items per launch and bt_api.cpp keeps items x longest path below 2^32 per workgroup.)
+    uint32_t segments = 0;
     unsigned long long lens_steps = 0;
     LensState lens;                    // lens extension: the bent segment in progress (LENS builds only)
     bool bent = false;
@@ -312,197 +345,41 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         } else {
             value = first;
         }
-        if (!SLICED) {
-            acc = acc + value;
-            k += 1;
-        } else if (!STREAM) {
-            ((Parked *)P.scratch + (size_t)bi * n_items)[park_i] = Parked{value.x, value.y, value.z};
-        } else {
-            if (P.ring_lds) {
-                float *dst = ring_l + 3u * park_idx;
-                dst[0] = value.x; dst[1] = value.y; dst[2] = value.z;
-            } else {
-                ((Parked *)P.scratch)[(size_t)blockIdx.x * ring_items + park_idx] = Parked{value.x, value.y, value.z};
-            }
-            item_flags |= 1u;                              // finished: counted at the next hand-out
-        }
+        if (FLOW) ((Parked *)P.scratch)[park_i] = Parked{value.x, value.y, value.z};
+        else ((Parked *)P.scratch + (size_t)blockIdx.x * n_items)[park_i] = Parked{value.x, value.y, value.z};
     };
 
-    // ---- streaming queue (QMODE 2) -------------------------------------------------------------------------------
-    // The launch is gridDim.x persistent workgroups; each claims pixel blocks (a block = pxb pixels of a tile, as in the
-    // block queue) one ahead of its need from a counter in HBM, so the blocks go to whoever is free -- a static deal
-    // (block w + n G to workgroup w) aliases with the tile rows and left the SIMDs 36 % empty on average
-    // (profiles/r02e/pmc_C3_q2_static.json).  A block's T samples are cut into n_chunks chunks of <= chunk_T; a
-    // UNIT = one block x one chunk = up to unit_cap items, and the workgroup's items are simply its units back to back:
-    // ONE counter in LDS hands them out, so a lane that has finished a sample flows on into the next unit -- and the next
-    // block -- without the drain at the end of every block that the block queue pays (10 % of all lane slots on
-    // volume.json, 28 % on the 512 x 512 Cornell box: profiles/r02d/lanestat_block_queue.log).  Sample values are parked
-    // in a ring of ring_slots unit-sized slots (LDS when it fits, else a small slice of HBM scratch per workgroup); the
-    // wave that finishes a unit's last item adds the unit to the running sums in sample order -- units strictly in
-    // sequence, so a pixel's chunks add up in order -- and only then may items of the unit ring_slots further on start.
-    const uint32_t R_MASK = STREAM ? (uint32_t)P.ring_slots - 1u : 0u;           // ring_slots is 2 or 4
-    const uint32_t LOG_PXB = STREAM ? (uint32_t)__builtin_ctz(pxb) : 0u;
-    const uint32_t n_chunks = STREAM ? (uint32_t)P.n_chunks : 1u, chunk_T = STREAM ? (uint32_t)P.chunk_T : T;
-    const uint32_t last_T = T - chunk_T * (n_chunks - 1u);                      // samples of a block's last chunk
-#ifdef BT_STREAM_DEBUG
-    unsigned long long dbg_spins = 0, dbg_blocked = 0, dbg_iters = 0;
-#endif
-    // Makes sure this workgroup's blocks 0 .. upto have been claimed (wave-uniform; called when a wave's cursor enters
-    // block upto - 2, so the claim -- one global atomic, microseconds -- is long done when the first lane needs it).
-    auto ensure_claimed = [&](uint32_t upto) {
-        unsigned long long act;
-        asm volatile("s_mov_b64 %0, exec" : "=s"(act));
-        const int first = __ffsll((long long)act) - 1;
-        for (;;) {
-            BT_LDS_FENCE();
-            uint32_t nc = 0, end = 0, got = 1;
-            if ((int)lane == first) {
-                nc = __hip_atomic_load(&s_nclaimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                end = __hip_atomic_load(&s_end_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            nc = (uint32_t)__builtin_amdgcn_readlane((int)nc, first);
-            end = (uint32_t)__builtin_amdgcn_readlane((int)end, first);
-            if (nc > upto || end <= upto) break;                                  // claimed, or the launch has no blocks left
-            if ((int)lane == first) got = atomicCAS(&s_claim_lock, 0u, 1u);
-            got = (uint32_t)__builtin_amdgcn_readlane((int)got, first);
-            if (got != 0u) {                                                      // another wave is claiming
-#ifdef BT_STREAM_DEBUG
-                dbg_spins += 1;
-                if (dbg_spins > 200000ull) {
-                    if ((int)lane == first) atomicMax(&P.counters[8], (1ull << 60) | ((unsigned long long)upto << 40) | ((unsigned long long)nc << 20) | (end & 0xfffffu));
+    // ---- flow queue (BtLaunch::flow): persistent workgroups that claim pixel blocks -------------------------------------
+    // The launch is gridDim.x workgroups (a few per CU); each claims blocks one ahead of its need from a counter in HBM,
+    // so the blocks go to whoever is free.  The workgroup's items are its blocks' items back to back -- ONE counter in
+    // LDS hands them out, so a lane that has finished a sample flows on into the next block without the drain at the end
+    // of every block that the block queue pays (28 % of all lane slots on the 512 x 512 Cornell box,
+    // profiles/r02d/lanestat_block_queue.log).  Nothing is summed here: every value is parked at
+    // scratch[block * n_items + i] and bt_sum_parked_kernel adds them up afterwards.
+    // The wave's cursor: the block (sequence number n in this workgroup's walk) that holds the items it was handed last.
+    uint32_t u_n = 0, u_start = 0;                     // wave-uniform
+    uint32_t b_cur = 0xffffffffu, b_nxt = 0xffffffffu; // the cursor's block and the one after it (launch order; 0xffffffff: none)
+    if (FLOW) __syncthreads();                         // s_blk[0], s_blk[1] of the prologue
+    // Makes sure this workgroup's n-th block has been claimed (wave-uniform; called when the cursor enters block n - 1,
+    // so the claim -- one global atomic, a microsecond -- is long done when a lane needs it).  s_blk holds the last four.
+    auto ensure_claimed = [&](uint32_t n) {
+        const int first_lane = __ffsll((long long)exec_here()) - 1;
+        if ((int)lane == first_lane) {
+            // one wave at a time moves s_nclaimed from n to n + 1: compare-and-swap through a "claiming" marker in the top bit
+            for (;;) {
+                const uint32_t nc = __hip_atomic_load(&s_nclaimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((nc & 0x7fffffffu) > n) break;                                     // claimed (by this or another wave)
+                if (nc == n && atomicCAS(&s_nclaimed, n, n | 0x80000000u) == n) {
+                    const uint32_t b = atomicAdd(P.block_counter, 1u);
+                    __hip_atomic_store(&s_blk[n & 3u], b < P.n_blocks ? b : 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    BT_LDS_FENCE();
+                    __hip_atomic_store(&s_nclaimed, n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     break;
                 }
-#endif
-                __builtin_amdgcn_s_sleep(4);
-                continue;
+                __builtin_amdgcn_s_sleep(2);                                           // another wave is claiming block n
             }
-            BT_LDS_FENCE();
-            if ((int)lane == first) {
-                nc = __hip_atomic_load(&s_nclaimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                end = __hip_atomic_load(&s_end_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (nc <= upto && end > upto) {
-                    const uint32_t b = atomicAdd(P.block_counter, 1u);
-                    if (b < P.n_blocks) {
-                        __hip_atomic_store(&s_blk[nc & 15u], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local");
-                        atomicAdd(&s_nclaimed, 1u);
-                    } else {
-                        __hip_atomic_store(&s_end_local, nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // blocks nc, nc + 1, ... do not exist
-                    }
-                }
-            }
-            BT_LDS_FENCE();
-            if ((int)lane == first) atomicExch(&s_claim_lock, 0u);
         }
-    };
-    // the wave's cursor: the unit that holds the items it was handed last (wave-uniform)
-    uint32_t u_seq = 0, u_start = 0, u_blk = 0, u_chunk = 0, u_items = pxb * (n_chunks == 1u ? T : chunk_T);
-    uint32_t sum_cache = 0;                                                     // the wave's last look at s_summed
-    // pixel q of block b (launch order) -- locate() with the block a per-lane value and every division a shift
-    auto locate_stream = [&](uint32_t b, uint32_t q) -> PixelRef {
-        const uint32_t slot = b >> LOG_NS, sub = b & (NS - 1u);
-        uint32_t bx, by;
-        if (LOG_PXB >= 6) {
-            const uint32_t quad = ((sub << LOG_PXB) + q) >> 6;
-            bx = ((quad & 1u) << 3) | (q & 7u);
-            by = ((quad >> 1) << 3) | ((q & 63u) >> 3);
-        } else {                                                                  // 8x4, 4x4, 4x2 pixels
-            const uint32_t lbw = LOG_PXB >= 5 ? 3u : 2u, lbh = LOG_PXB > lbw ? LOG_PXB - lbw : 0u, lnbx = 4u - lbw;
-            bx = ((sub & ((1u << lnbx) - 1u)) << lbw) + (q & ((1u << lbw) - 1u));
-            by = ((sub >> lnbx) << lbh) + (q >> lbw);
-        }
-        const uint32_t tile = P.sharded ? (slot * P.world + P.rank) : slot;
-        uint32_t ty = __umulhi(tile, P.tiles_x_magic), tx = tile - ty * P.tiles_x;   // tile / tiles_x, exact after the fix-up
-        if (tx >= P.tiles_x) { ty += 1u; tx -= P.tiles_x; }
-        PixelRef r;
-        r.px = tx * BT_TILE_DIM + bx;
-        r.py = ty * BT_TILE_DIM + by;
-        r.in_frame = (ty < P.tiles_y) && (r.px < P.width) && (r.py < P.height);
-        r.out = P.sharded ? P.out + ((size_t)slot * (BT_TILE_DIM * BT_TILE_DIM) + by * BT_TILE_DIM + bx) * 4
-                          : P.out + ((size_t)r.py * P.width + r.px) * 4;
-        return r;
-    };
-    // Adds every complete unit, in sequence, to the running sums: `*r += pixel.r` (buffer.rs:159-164) in sample order.
-    // Called by a whole wave (every lane still in the loop) right after it finished a unit's last item.
-    auto sum_ready_units = [&]() {
-        // the lanes that execute THIS code: read EXEC in place (a `__ballot(true)` is an expression the optimizer may
-        // evaluate earlier in the iteration, where lanes that have since left for the loop head still count)
-        unsigned long long act;
-        asm volatile("s_mov_b64 %0, exec" : "=s"(act));
-        const int first = __ffsll((long long)act) - 1;
-        for (;;) {
-            // The protocol words s_summed / s_ready / s_done live in LDS and every access to them is ordered against the
-            // next by a sequentially consistent LDS fence: "my ready bit is set" must be visible before this wave looks at
-            // s_summed, and "s_summed has moved on" before it looks at the next unit's ready bit -- with relaxed atomics the
-            // compiler may swap two accesses to different words, and then a unit that completed out of order is left for
-            // a later completion to find (or, at the end of the workgroup's walk, for nobody).
-            BT_LDS_FENCE();
-            uint32_t cur = 0, was = 0;
-            if ((int)lane == first) cur = __hip_atomic_load(&s_summed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            cur = (uint32_t)__builtin_amdgcn_readlane((int)cur, first);
-            const uint32_t r = cur & R_MASK;
-            BT_LDS_FENCE();
-            if ((int)lane == first) was = atomicAnd(&s_ready, ~(1u << r));
-            was = (uint32_t)__builtin_amdgcn_readlane((int)was, first);
-            if (!(was & (1u << r))) break;                                        // not complete yet, or another wave has it
-            BT_LDS_FENCE();
-            if (!P.ring_lds) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // parked values in HBM: other waves' stores
-            const uint32_t blk = n_chunks == 1u ? cur : cur / n_chunks, chunk = cur - blk * n_chunks;
-            const uint32_t b = __hip_atomic_load(&s_blk[blk & 15u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t Tcu = chunk == n_chunks - 1u ? last_T : chunk_T;
-            const bool first_chunk = chunk == 0u, last_chunk = chunk == n_chunks - 1u;
-
-            // The lanes that execute the pixel loop, read where it starts: the compiler structures this for (;;) as a loop with
-            // divergent exits and may have taken lanes out of EXEC by the second trip (seen on the MI355X: the mask read at
-            // the top of the function differed in ~1 % of the sums, and the pixels of the missing ranks were skipped).
-            unsigned long long act2;
-            asm volatile("s_mov_b64 %0, exec" : "=s"(act2));
-            const uint32_t n_act2 = (uint32_t)__popcll(act2);
-            const uint32_t rank2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act2, 0u));
-            for (uint32_t q = rank2; q < pxb; q += n_act2) {
-                const PixelRef pr = locate_stream(b, q);
-                V3 sum = mk(0.0f, 0.0f, 0.0f);
-                if (first_chunk) {
-                    if (pr.in_frame) sum = mk(pr.out[0], pr.out[1], pr.out[2]);
-                } else {
-                    sum = mk(s_accum[3u * q], s_accum[3u * q + 1u], s_accum[3u * q + 2u]);
-                }
-                if (pr.in_frame) {
-                    const uint32_t base_idx = r * P.unit_cap + q;
-                    if (P.ring_lds) {
-                        const float *src = ring_l + 3u * base_idx;
-                        for (uint32_t kk = 0; kk < Tcu; ++kk) {
-                            const float *v = src + 3u * (kk << LOG_PXB);
-                            sum = sum + mk(v[0], v[1], v[2]);
-                        }
-                    } else {
-                        const Parked *src = (const Parked *)P.scratch + (size_t)blockIdx.x * ring_items + base_idx;
-                        uint32_t kk = 0;
-                        for (; kk + 8 <= Tcu; kk += 8) {           // eight loads in flight, additions strictly in order
-                            Parked v[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j) << LOG_PXB];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
-                        }
-                        for (; kk < Tcu; ++kk) {
-                            const Parked v = src[(size_t)kk << LOG_PXB];
-                            sum = sum + mk(v.x, v.y, v.z);
-                        }
-                    }
-                }
-                if (last_chunk) {
-                    if (pr.in_frame) { pr.out[0] = sum.x; pr.out[1] = sum.y; pr.out[2] = sum.z; }
-                } else {
-                    s_accum[3u * q] = sum.x; s_accum[3u * q + 1u] = sum.y; s_accum[3u * q + 2u] = sum.z;
-                }
-            }
-            // the slot is free again: the unit ring_slots further on may start
-            BT_LDS_FENCE();
-            if ((int)lane == first) atomicExch(&s_done[r], 0u);
-            BT_LDS_FENCE();
-            if ((int)lane == first) atomicAdd(&s_summed, 1u);
-        }
+        BT_LDS_FENCE();
     };
 
     BT_PROF_DECL;
@@ -511,9 +388,6 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     const unsigned long long ls_all = __ballot(true);
 #endif
     while (alive) {
-#ifdef BT_STREAM_DEBUG
-        dbg_iters += 1;
-#endif
         BT_LS(0, 1ull);
         BT_LS(8, ls_all & ~__ballot(true));
         BT_PROF(0);                                       // loop overhead / previous iteration's tail
@@ -634,33 +508,19 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         pending = false;
 
         if (VOTE && P.phase_vote) {
-            // ---- which events run this iteration?  The kind more lanes want; nobody waits more than max_wait iterations.
-            // Two kinds in builds without volumes (camera | scatter); three with them (camera | surface scatter | volume
-            // step): where paths march, the volume steps are most of a wave's events and the few surface lanes wait for
-            // company instead of dragging the Diffuse / light-pdf blocks through every iteration.
+            // ---- which events run this iteration?  The kind more lanes want (camera | scatter / volume step); nobody waits
+            // more than max_wait iterations.  Everything here is wave-uniform mask arithmetic on the scalar unit; the lane's
+            // verdict is its bit of `served_m`.
             const bool want_gen = ev == EV_GEN;
-            const bool want_vol = VOLS && BT_VOTE3 && ev == EV_VOLUME;
-            const bool want_sc = !want_gen && !want_vol;
-            const unsigned long long m_gen = __ballot(want_gen), m_sc = __ballot(want_sc), m_vol = (VOLS && BT_VOTE3) ? __ballot(want_vol) : 0ull;
-            const int n_gen = __popcll(m_gen), n_sc = __popcll(m_sc), n_vol = __popcll(m_vol);
-            // a lane of a losing side that has waited long enough is served in THIS iteration together with the winners
+            const unsigned long long m_gen = __ballot(want_gen), m_sc = __ballot(!want_gen);
+            const uint32_t n_gen = popc64(m_gen), n_sc = popc64(m_sc);
+            // a lane of the losing side that has waited long enough is served in THIS iteration together with the winners
             // (its whole kind runs, as without the vote) -- the majority does not lose an iteration to it
             const unsigned long long starving = __ballot(waited >= P.phase_vote);
-            const bool run_gen = (n_gen >= n_sc && n_gen >= n_vol) || (starving & m_gen) != 0;
-            const bool run_sc = (n_sc > n_gen && n_sc >= n_vol) || (starving & m_sc) != 0;
-            const bool run_vol = (n_vol > n_gen && n_vol > n_sc) || (starving & m_vol) != 0;
-            bool served = want_gen ? run_gen : (want_vol ? run_vol : run_sc);
-#if BT_VOTE_SOFT_K > 0
-            // soft batching (A/B knob): in builds with volumes a surface event (Diffuse / Metallic / Glass) that shares its
-            // wave with march steps waits until BT_VOTE_SOFT_K surface lanes have gathered (or one of them has waited
-            // long enough): the march steps never wait for it
-            if (VOLS && !BT_VOTE3) {
-                const bool surf = want_sc && ev != EV_VOLUME;
-                const unsigned long long m_surf = __ballot(surf);
-                const bool run_surf = __popcll(m_surf) >= BT_VOTE_SOFT_K || (starving & m_surf) != 0 || m_surf == m_sc;
-                if (surf && !run_surf) served = false;
-            }
-#endif
+            const bool run_gen = n_gen >= n_sc || (starving & m_gen) != 0;
+            const bool run_sc = n_sc > n_gen || (starving & m_sc) != 0;
+            const unsigned long long served_m = (run_gen ? m_gen : 0ull) | (run_sc ? m_sc : 0ull);
+            const bool served = __builtin_amdgcn_inverse_ballot_w64(served_m);
             BT_LS(7, __ballot(!served));
             if (!served) {
                 waited += 1;
@@ -673,126 +533,53 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         }
 
         // ---- a lane whose path has ended (or that has none yet) moves on to its next sample ----
-        if (!SLICED) {
-            if (ev == EV_GEN && k >= T) break;                            // this pixel is done
-        } else if (STREAM) {
-            // the lanes that execute THIS code: EXEC read in place.  Every ballot below is masked with it -- a ballot is an
-            // expression the optimizer may evaluate earlier in the iteration, where lanes that have since gone back to the
-            // loop head (phase vote, waiting for a ring slot) still take part; counting one of those here would count its
-            // finished sample twice.
-            unsigned long long here;
-            asm volatile("s_mov_b64 %0, exec" : "=s"(here));
-            // (1) count the samples that have just ended: one LDS atomic per wave and ring slot; the wave that brings a
-            //     unit to its full count adds it (and every complete unit behind it) to the running sums
-            if (__ballot((item_flags & 1u) != 0u) & here) {
-                // the parked values before the count: LDS stores are ordered by the LDS fence; stores to the HBM ring
-                // have to be waited for (vmcnt)
-                if (P.ring_lds) BT_LDS_FENCE(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                for (uint32_t r = 0; r <= R_MASK; ++r) {
-                    const unsigned long long m = __ballot((item_flags & 1u) != 0u && (my_unit & R_MASK) == r) & here;
-                    if (!m) continue;                                     // wave-uniform
-                    const int leader = __ffsll((long long)m) - 1;
-                    const uint32_t cnt = (uint32_t)__popcll(m);
-                    uint32_t old_cnt = 0;
-                    if ((int)lane == leader) old_cnt = atomicAdd(&s_done[r], cnt);
-                    old_cnt = (uint32_t)__builtin_amdgcn_readlane((int)old_cnt, leader);
-                    const uint32_t unit_items = (uint32_t)__builtin_amdgcn_readlane((int)((item_flags & 4u) ? pxb * last_T : P.unit_cap), leader);
-                    if (old_cnt + cnt == unit_items) {
-                        BT_LDS_FENCE();
-                        if ((int)lane == leader) atomicOr(&s_ready, 1u << r);
-                        sum_ready_units();
-                    }
-                }
-                item_flags &= ~1u;
-            }
-            // (2) hand out new items
-            const bool want_item = ev == EV_GEN && !(item_flags & 2u);
-            const unsigned long long need = __ballot(want_item) & here;
-            if (need) {
-                const int leader = __ffsll((long long)need) - 1;
-                uint32_t base = 0;
-                if ((int)lane == leader) base = atomicAdd(&s_next_item, (uint32_t)__popcll(need));
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                while (base >= u_start + u_items) {                       // move the wave's cursor to the unit that holds `base`
-                    u_start += u_items;
-                    u_seq += 1u;
-                    u_chunk += 1u;
-                    if (u_chunk == n_chunks) {
-                        u_chunk = 0u;
-                        u_blk += 1u;
-                        ensure_claimed(u_blk + 2u);                       // this block and the two after it
-                    }
-                    u_items = pxb * (u_chunk == n_chunks - 1u ? last_T : chunk_T);
-                }
-                if (want_item) {
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
-                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                    const uint32_t j = base + below;
-                    // a unit holds >= 64 items: the wave's 64 items lie in the cursor's unit or in the one after it
-                    const bool nxt = j >= u_start + u_items;
-                    const uint32_t n_chunk = u_chunk + 1u == n_chunks ? 0u : u_chunk + 1u;
-                    const uint32_t chunk_l = nxt ? n_chunk : u_chunk;
-                    const uint32_t blk_l = nxt && n_chunk == 0u ? u_blk + 1u : u_blk;
-                    const uint32_t within = j - (nxt ? u_start + u_items : u_start);
-                    my_unit = nxt ? u_seq + 1u : u_seq;
-                    k = chunk_l * chunk_T + (within >> LOG_PXB);
-                    park_idx = (my_unit & R_MASK) * P.unit_cap + within;
-                    if (blk_l >= *(volatile uint32_t *)&s_end_local) break;   // the launch has no blocks left: this lane is done
-                    const uint32_t gb = s_blk[blk_l & 15u];                 // claimed when the cursor entered block blk_l - 1
-                    const PixelRef r = locate_stream(gb, within & (pxb - 1u));
-                    px = r.px;
-                    py = r.py;
-                    item_flags = 2u | (chunk_l == n_chunks - 1u ? 4u : 0u) | (r.in_frame ? 8u : 0u);
-                }
-            }
-            // (3) a reserved item starts once its ring slot is free, i.e. the unit ring_slots before it has been summed
-            if (ev == EV_GEN) {
-                // s_summed only grows: the wave's copy is re-read only when it would hold a lane back
-                if (__ballot(my_unit > sum_cache + R_MASK) & here) sum_cache = *(volatile uint32_t *)&s_summed;
-                BT_LS(7, __ballot(my_unit > sum_cache + R_MASK) & here);   // (lanestat: counted with the phase waiters)
-                if (my_unit > sum_cache + R_MASK) {
-#ifdef BT_STREAM_DEBUG
-                    dbg_blocked += 1;
-                    if (dbg_blocked > 400000ull) {        // watchdog of the debug build: say where, and leave instead of hanging the GPU
-                        atomicMax(&P.counters[6], ((unsigned long long)my_unit << 40) | ((unsigned long long)(*(volatile uint32_t *)&s_summed) << 20) |
-                                                  ((unsigned long long)(*(volatile uint32_t *)&s_ready) << 16) | ((*(volatile uint32_t *)&s_done[(*(volatile uint32_t *)&s_summed) & R_MASK]) & 0xffffu));
-                        atomicMax(&P.counters[7], ((unsigned long long)(*(volatile uint32_t *)&s_nclaimed) << 40) | ((unsigned long long)(*(volatile uint32_t *)&s_end_local & 0xfffffu) << 20) | (*(volatile uint32_t *)&s_next_item & 0xfffffu));
-                        break;
-                    }
-#endif
-                    pending = true;
-                    continue;
-                }
-                item_flags &= ~2u;
-                if (!(item_flags & 8u)) {                                 // pixel outside the frame (edge tile): nothing to trace
-                    item_flags |= 1u;
-                    pending = true;
-                    continue;
-                }
-                pixel_index = py * P.width + px;
-            }
-        } else {
+        {
             const unsigned long long need = __ballot(ev == EV_GEN);
             if (need) {                                                   // one LDS atomic for the whole wave
                 const int leader = __ffsll((long long)need) - 1;
                 uint32_t base = 0;
                 if ((int)lane == leader) base = atomicAdd(&s_next_item, (uint32_t)__popcll(need));
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                if (FLOW) {
+                    // move the wave's cursor to the block that holds `base`; the block after it was claimed when the cursor
+                    // entered this one (a block holds >= 256 items: the wave's 64 items lie in the cursor's block or the next)
+                    while (base >= u_start + n_items) {
+                        u_start += n_items;
+                        u_n += 1u;
+                        ensure_claimed(u_n + 1u);
+                    }
+                    b_cur = __hip_atomic_load(&s_blk[u_n & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    b_nxt = __hip_atomic_load(&s_blk[(u_n + 1u) & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 if (ev == EV_GEN) {
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
-                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                    const uint32_t i = base + below;
-                    if (i >= n_items) break;                              // the block's samples are all taken
-                    const uint32_t q = i & (pxb - 1);
-                    const PixelRef r = locate(q);                         // (the sample number is park_i >> log2(pxb), see k_cur)
+                    uint32_t i = base + lanes_below(need);
+                    BlockRef B = B_own;
+                    if (FLOW) {
+                        i -= u_start;
+                        const bool nxt = i >= n_items;
+                        if (nxt) i -= n_items;
+                        const uint32_t b = nxt ? b_nxt : b_cur;
+                        if (b == 0xffffffffu) break;                      // the launch has no blocks left: this lane is done
+                        // the two blocks' places in the frame are wave-uniform (scalar); the lane picks its own
+                        const BlockRef Bc = block_ref(P, G, b_cur == 0xffffffffu ? 0u : b_cur), Bn = block_ref(P, G, b_nxt == 0xffffffffu ? 0u : b_nxt);
+                        B.px0 = nxt ? Bn.px0 : Bc.px0;
+                        B.py0 = nxt ? Bn.py0 : Bc.py0;
+                        B.tile_ok = nxt ? Bn.tile_ok : Bc.tile_ok;
+                        B.slot = nxt ? Bn.slot : Bc.slot;
+                        park_i = b * n_items + i;
+                    } else {
+                        if (i >= n_items) break;                          // the block's samples are all taken
+                        park_i = i;                                       // (+ the workgroup's base, see finish_sample)
+                    }
+                    const PixelRef r = pixel_of(P, G, B, i & (pxb - 1u));
                     px = r.px;
                     py = r.py;
+                    if (FLOW) k_cur = i >> LOG_PXB;
                     if (!r.in_frame) {
                         pending = true;                                   // pixel outside the frame (edge tile): skip it
                         continue;
                     }
                     pixel_index = py * P.width + px;
-                    park_i = i;
                 }
             }
         }
@@ -802,8 +589,8 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         BT_LS(5, __ballot(ev == EV_GLASS)); BT_LS(6, __ballot(ev == EV_VOLUME));
         // ---- the lane's one random event of this iteration (numerics contract N6) ----
         // block queue: the item's sample number comes out of its item number (one register less than keeping both)
-        const uint32_t k_cur = SLICED && !STREAM ? park_i >> LOG_PXB_ALL : k;
-        const uint32_t sample_index = sample0 + k_cur;
+        const uint32_t k_now = FLOW ? k_cur : park_i >> LOG_PXB;
+        const uint32_t sample_index = sample0 + k_now;
         const U4 u = philox(pixel_index, sample_index, ev == EV_GEN ? 0u : event, 0u, P.seed_lo, P.seed_hi);
         // slots of the two angular draws: Metallic [0],[1]; Glass [1],[2]; everything else [2],[3]
         const uint32_t w1 = ev == EV_METALLIC ? u.x : (ev == EV_GLASS ? u.y : u.z);
@@ -830,7 +617,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             float u_sub = 0.0f, v_sub = 0.0f;
             if (P.subsample_n > 1) {
                 const uint32_t n = (uint32_t)P.subsample_n;
-                const uint32_t subpx = k_cur % (n * n);
+                const uint32_t subpx = k_now % (n * n);
                 const float width_sub = 1.0f / (float)n;
                 u_sub = (float)(subpx % n) * width_sub;
                 v_sub = (float)(subpx / n) * width_sub;
@@ -1007,117 +794,34 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         }
         BT_PROF(5);                                       // normalize, pdf weight (light_pdf), bookkeeping
     }
-
-    if (in_frame && !SLICED) {
-        out_px[0] = acc.x;
-        out_px[1] = acc.y;
-        out_px[2] = acc.z;
+    // ---- the end of a workgroup --------------------------------------------------------------------------------------
+    // Block queue: the last wave of the workgroup to get here performs `*r += pixel.r` (buffer.rs:159-164) for every parked
+    // sample of the block's pixels, in sample order (sum_block).  The parked values were written by waves of this
+    // workgroup (same CU, same L1 / L2), so workgroup-scope release / acquire is all the ordering that is needed.  Flow
+    // queue: bt_sum_parked_kernel does the sums after this kernel; the last wave only reports the segment count.
+    if (P.counters) {
+        uint32_t sg = segments;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sg += __shfl_xor(sg, off, 64);
+        if (lane == 0 && sg) atomicAdd(&s_segments, sg);              // LDS; ahead of this wave's s_waves_done below
     }
-    if (SLICED && !STREAM) {
-        // The last wave of the workgroup to get here performs `*r += pixel.r` (buffer.rs:159-164) for every parked
-        // sample of the block's pixels, in sample order -- the additions the unsliced kernel performs in registers,
-        // in the same order.  The parked values were written by waves of this workgroup (same CU, same L1/L2), so
-        // workgroup-scope release / acquire is all the ordering that is needed.
-        if (WG_COUNT && P.counters && !BT_NO_COUNTERS) {
-            uint32_t sg = (uint32_t)segments;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) sg += __shfl_xor(sg, off, 64);
-            if (lane == 0 && sg) atomicAdd(&s_segments, sg);          // LDS; ahead of this wave's s_waves_done below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&s_waves_done, 1u);
+    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+    if (arrived == (blockDim.x >> 6) - 1u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (P.counters && lane == 0) {
+            const uint32_t total = *(volatile uint32_t *)&s_segments;
+            if (total) atomicAdd(&P.counters[0], (unsigned long long)total);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        uint32_t arrived = 0;
-        if (lane == 0) arrived = atomicAdd(&s_waves_done, 1u);
-        arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
-        if (arrived == (blockDim.x >> 6) - 1u) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (WG_COUNT && P.counters && !BT_NO_COUNTERS && lane == 0) {
-                const uint32_t total = *(volatile uint32_t *)&s_segments;
-                if (total) atomicAdd(&P.counters[0], (unsigned long long)total);
-            }
-            if (pxb >= 64) {
-                for (uint32_t q = lane; q < pxb; q += 64) {
-                    const PixelRef r = locate(q);
-                    if (!r.in_frame) continue;
-                    float *o = r.out;
-                    const Parked *src = (const Parked *)P.scratch + (size_t)bi * T * pxb + q;
-                    V3 sum = mk(o[0], o[1], o[2]);
-                    uint32_t kk = 0;
-                    for (; kk + 8 <= T; kk += 8) {             // eight loads in flight, additions strictly in order
-                        Parked v[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j) * pxb];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
-                    }
-                    for (; kk < T; ++kk) {
-                        const Parked v = src[(size_t)kk * pxb];
-                        sum = sum + mk(v.x, v.y, v.z);
-                    }
-                    o[0] = sum.x;
-                    o[1] = sum.y;
-                    o[2] = sum.z;
-                }
-            } else {
-                // 32, 16 or 8 pixels (deep launches, T in the hundreds): J = 64 / pxb lanes per pixel fetch interleaved
-                // samples (8 J in flight per pixel), lane (q, 0) adds them in sample order out of the others' registers
-                const uint32_t J = 64u >> LOG_PXB_ALL, q = lane & (pxb - 1u), jl = lane >> LOG_PXB_ALL;
-                const PixelRef r = locate(q);
-                const bool owner = jl == 0 && r.in_frame;
-                float *o = r.out;
-                const Parked *src = (const Parked *)P.scratch + (size_t)bi * T * pxb + q;
-                V3 sum = mk(0.0f, 0.0f, 0.0f);
-                if (owner) sum = mk(o[0], o[1], o[2]);
-                for (uint32_t kk = 0; kk < T; kk += 8 * J) {
-                    Parked v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const uint32_t k2 = kk + (uint32_t)u * J + jl;
-                        v[u] = k2 < T ? src[(size_t)k2 * pxb] : Parked{0.0f, 0.0f, 0.0f};
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        for (uint32_t jj = 0; jj < J; ++jj) {
-                            const int from = (int)(q + jj * pxb);
-                            const V3 val = mk(__shfl(v[u].x, from, 64), __shfl(v[u].y, from, 64), __shfl(v[u].z, from, 64));
-                            if (kk + (uint32_t)u * J + jj < T) sum = sum + val;
-                        }
-                }
-                if (owner) {
-                    o[0] = sum.x;
-                    o[1] = sum.y;
-                    o[2] = sum.z;
-                }
-            }
-        }
+        if (!FLOW) sum_block(P, G, blockIdx.x, T, (const Parked *)P.scratch + (size_t)blockIdx.x * n_items, lane);
     }
-    if (P.counters && !BT_NO_COUNTERS) {
-        if (!WG_COUNT) {
-            unsigned long long s = wave_sum((unsigned long long)segments);
-            if (lane == 0 && s) atomicAdd(&P.counters[0], s);
-        }
+    if (P.counters) {
         if (LENS) {
             unsigned long long ls = wave_sum(lens_steps);
             if (lane == 0 && ls) atomicAdd(&P.counters[1], ls);
         }
-#ifdef BT_STREAM_DEBUG
-        {   // debug build: lane-iterations | lane-iterations spent waiting for a ring slot | wave spins on the claim lock
-            const unsigned long long a = wave_sum(dbg_iters), b = wave_sum(dbg_blocked), c = wave_sum(dbg_spins);
-            if (lane == 0) { atomicAdd(&P.counters[3], a); atomicAdd(&P.counters[4], b); atomicAdd(&P.counters[5], c); }
-        }
-#endif
-#ifdef BT_XCCSTAT
-        {   // developer build: when the last wave of every XCD ends (s_memrealtime, 100 MHz), and when the first wave starts
-            const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;   // HW_REG_XCC_ID[3:0]
-            const unsigned long long t = wall_clock64();
-#if BT_XCCSTAT == 2
-            if (threadIdx.x == 0) atomicAdd(&P.counters[2 + xcc], 1ull);      // workgroups per XCD instead
-            (void)t;
-            if (lane == 0) atomicMax(&P.counters[10], ~xcc_t0);
-#else
-            if (lane == 0) { atomicMax(&P.counters[2 + xcc], t); atomicMax(&P.counters[10], ~xcc_t0); }
-#endif
-        }
-#endif
 #ifdef BT_LANESTAT
         for (int i = 0; i < 9; ++i) {
             unsigned long long v = ls_acc[i];
@@ -1132,6 +836,13 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             for (int i = 0; i < BT_N_COUNTERS - 2; ++i) atomicAdd(&P.counters[2 + i], prof_acc[i]);
 #endif
     }
+}
+
+// Flow queue, second kernel: the ordered per-pixel sums over the parked values (sum_block), one wave per pixel block.
+__global__ __launch_bounds__(64) void bt_sum_parked_kernel(BtLaunch P) {
+    const BlockGeom G = block_geom(P);
+    const uint32_t T = (uint32_t)P.samples * (uint32_t)(P.subsample_n * P.subsample_n);
+    sum_block(P, G, blockIdx.x, T, (const Parked *)P.scratch + (size_t)blockIdx.x * G.pxb * T, threadIdx.x);
 }
 
 // shard (tile-major, `world` ranks back to back) -> row-major frame; rgb AND alpha copied.
@@ -1210,42 +921,44 @@ __global__ __launch_bounds__(256) void bt_preview_kernel(const float4 *rgba, uin
 // ---- host-side launchers (called from bt_api.cpp) ---------------------------------------------
 extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream) {
-    // grid = tiles to render; with sample slicing a tile is S workgroups (see the mapping in the kernel); the streaming
-    // queue launches P->stream_grid persistent workgroups instead
-    const unsigned tpw = P->scratch || P->stream ? (unsigned)P->tiles_per_wg : 1u;
-    dim3 g(P->stream ? P->stream_grid : (tpw > 1 ? (grid + tpw - 1) / tpw : grid * (unsigned)P->slices)), b(P->scratch && !P->stream ? BT_WG_THREADS : 256);
-    // 0 = a lane owns a pixel, 1 = block queue (parks in scratch), 2 = streaming queue; the lens builds have no streaming
-    // instantiation (bt_api.cpp does not ask for one)
-    const int qmode = P->stream ? 2 : (P->scratch != nullptr ? 1 : 0);
+    // block queue: grid = tiles to render, a tile is P->slices workgroups (see the mapping in the kernel); flow queue:
+    // P->flow_grid persistent workgroups, then one wave per pixel block for the ordered sums
+    dim3 g(P->flow ? P->flow_grid : grid * (unsigned)P->slices), b(256);
     // scene classes: bit 0 = some sphere carries a volume (volume.json, cloud.json), bit 1 = rects / cuboids present
     // (the Cornell boxes); scene.json is class 0
     const int cls = (P->any_rects ? 2 : 0) | (P->any_volumes ? 1 : 0);
     // scene tables beyond the default 64 KB of dynamic LDS (hundreds of objects): gfx950 has 160 KB per CU, the limit
     // has to be raised per kernel; one workgroup per CU is then all that fits
-#define BT_LAUNCH(O, L, S, R, V)                                                                                 \
+#define BT_LAUNCH(O, L, R, V, F)                                                                                 \
     do {                                                                                                         \
         if (lds_bytes > 48 * 1024)                                                                               \
-            (void)hipFuncSetAttribute((const void *)bt_render_kernel<O, L, S, R, V>,                             \
+            (void)hipFuncSetAttribute((const void *)bt_render_kernel<O, L, R, V, F>,                             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
-        hipLaunchKernelGGL((bt_render_kernel<O, L, S, R, V>), g, b, lds_bytes, stream, *P);                      \
+        hipLaunchKernelGGL((bt_render_kernel<O, L, R, V, F>), g, b, lds_bytes, stream, *P);                      \
     } while (0)
-#define BT_LAUNCH_OUT(L, S, R, V)                                                                                \
+#define BT_LAUNCH_OUT(L, R, V)                                                                                   \
     switch (output) {                                                                                            \
-    case 0: BT_LAUNCH(0, L, S, R, V); break;                                                                     \
-    case 1: BT_LAUNCH(1, L, S, R, V); break;                                                                     \
-    case 2: BT_LAUNCH(2, L, S, R, V); break;                                                                     \
-    default: BT_LAUNCH(3, L, S, R, V); break;                                                                    \
+    case 0: BT_LAUNCH(0, L, R, V, false); break;                                                                 \
+    case 1: BT_LAUNCH(1, L, R, V, false); break;                                                                 \
+    case 2: BT_LAUNCH(2, L, R, V, false); break;                                                                 \
+    default: BT_LAUNCH(3, L, R, V, false); break;                                                                \
     }
-#define BT_LAUNCH_RECTS(L, S)                                                                                    \
-    if (cls == 3) { BT_LAUNCH_OUT(L, S, true, true) } else if (cls == 2) { BT_LAUNCH_OUT(L, S, true, false) }      \
-    else if (cls == 1) { BT_LAUNCH_OUT(L, S, false, true) } else { BT_LAUNCH_OUT(L, S, false, false) }
-    if (P->lens_on) {
-        if (qmode == 2) return hipErrorInvalidValue;
-        if (qmode == 1) { BT_LAUNCH_RECTS(true, 1) } else { BT_LAUNCH_RECTS(true, 0) }
+#define BT_LAUNCH_CLASS(L)                                                                                       \
+    if (cls == 3) { BT_LAUNCH_OUT(L, true, true) } else if (cls == 2) { BT_LAUNCH_OUT(L, true, false) }            \
+    else if (cls == 1) { BT_LAUNCH_OUT(L, false, true) } else { BT_LAUNCH_OUT(L, false, false) }
+    if (P->flow) {                                  // Output::Full without the lens (bt_api.cpp asks for nothing else)
+        if (P->lens_on || output != 0) return hipErrorInvalidValue;
+        if (cls == 3) BT_LAUNCH(0, false, true, true, true); else if (cls == 2) BT_LAUNCH(0, false, true, false, true);
+        else if (cls == 1) BT_LAUNCH(0, false, false, true, true); else BT_LAUNCH(0, false, false, false, true);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bt_sum_parked_kernel, dim3(P->n_blocks), dim3(64), 0, stream, *P);
+    } else if (P->lens_on) {
+        BT_LAUNCH_CLASS(true)
     } else {
-        if (qmode == 2) { BT_LAUNCH_RECTS(false, 2) } else if (qmode == 1) { BT_LAUNCH_RECTS(false, 1) } else { BT_LAUNCH_RECTS(false, 0) }
+        BT_LAUNCH_CLASS(false)
     }
-#undef BT_LAUNCH_RECTS
+#undef BT_LAUNCH_CLASS
 #undef BT_LAUNCH_OUT
 #undef BT_LAUNCH
     return hipGetLastError();

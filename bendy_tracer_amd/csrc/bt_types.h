@@ -10,7 +10,7 @@
 #define BT_N_COUNTERS 2
 #endif
 #define BT_DENSITY_LDS_MAX 8192   // density maps up to this many cells are staged in LDS (32 KB)
-#define BT_BLOCK_COUNTER_SLOT 15 // d_counters[15] is the streaming queue's block counter (the array holds 16 words)
+#define BT_BLOCK_COUNTER_SLOT 15 // d_counters[15] is the flow queue's block counter (the array holds 16 words)
 
 struct BtV3 { float x, y, z; };
 
@@ -191,28 +191,21 @@ struct BtLaunch {
     int32_t sharded;                  // 0: out = row-major frame; 1: out = this rank's shard
     float *out;
     unsigned long long *counters;     // [0] path segments, [1] lens RK4 steps
-    // Sample slicing (bt_api.cpp decides).  With one lane per pixel a wave lives for all of its pixels' samples,
-    // which leaves a long ragged tail at the end of a launch and, for launches with few pixels and many samples (a
-    // rank's shard under multi-GPU weak scaling), not enough waves to fill the GPU.  With slices = S in {2,4,8,16} a
-    // workgroup is 256/S pixels x S slices of the samples; every sample's value is parked in
-    // scratch[(block * T + k) * (256/S) + pixel] (float4, T = samples * n^2) and the last wave of the workgroup to
-    // finish adds them to the frame in sample order -- same additions, same order, same bits as slices = 1.
-    int32_t slices;                   // 1 = a lane owns all samples of its pixel (no scratch)
-    int32_t tiles_per_wg;             // work-queue kernel, shallow launches: a workgroup owns 1, 2 or 4 whole tiles (slices == 1)
+    // The work queue (bt_api.cpp decides its shape).  A 16x16 tile is cut into `slices` = S in {1,2,4,8,16,32} pixel blocks
+    // of 256/S pixels; a block's (pixel, sample) pairs are dealt to the lanes of a workgroup, every sample's value is parked
+    // in scratch[(block * T + k) * (256/S) + pixel] (12 bytes, T = samples * n^2) and added to the frame in sample order --
+    // the additions a lane that owned the pixel would perform, in the same order, hence the same bits.
+    int32_t slices;
     float *scratch;
-    // Streaming queue (bt_kernels.hip "streaming"; bt_api.cpp decides): the launch is stream_grid persistent workgroups,
-    // workgroup w walks the pixel blocks w, w + stream_grid, ...; a block's samples are cut into n_chunks chunks of
-    // <= chunk_T; the values of a unit (block x chunk, <= unit_cap items) are parked in one of ring_slots slots -- in LDS
-    // behind the scene tables (ring_lds) or at scratch[workgroup * ring_slots * unit_cap ...] (float4 each).
-    int32_t stream;                   // 1: streaming queue (slices = blocks per tile, 4 .. 32; tiles_per_wg = 1)
-    int32_t ring_slots;               // 2 or 4
-    int32_t ring_lds;
-    int32_t chunk_T, n_chunks;
+    // Flow queue (shallow launches): the launch is flow_grid persistent workgroups that claim pixel blocks from
+    // *block_counter (zeroed before every launch) and deal each block's pairs the same way without waiting for a block's
+    // slowest path; bt_sum_parked_kernel does the ordered sums afterwards.  0: block queue -- workgroup b owns block b and
+    // its last wave sums it.
+    int32_t flow;
     uint32_t n_blocks;                // pixel blocks of this launch = tiles of the launch * slices
-    uint32_t unit_cap;                // (256 / slices) * chunk_T
-    uint32_t stream_grid;
-    uint32_t *block_counter;          // next unclaimed pixel block of the launch (zeroed before every launch)
-    uint32_t tiles_x_magic;           // floor(2^32 / tiles_x) + 1: tile / tiles_x = umulhi(tile, magic), fixed up by one step
+    uint32_t flow_grid;
+    uint32_t *block_counter;
+    uint32_t tiles_x_magic;           // floor(2^32 / tiles_x) (0xffffffff for tiles_x = 1): tile / tiles_x = umulhi(tile, magic), fixed up by one step
     uint32_t table_lds_bytes;         // bytes of the scene tables at the start of dynamic LDS
     // Scenes with volumes: behind the tables one BtVolBox per primitive (48 B; filled by the kernel's prologue for the
     // spheres that carry a volume): the bounding box Volume::shade divides by (volume.rs:26-35, sphere.rs:35-38) and the

@@ -81,28 +81,29 @@ typedef struct {
     uint64_t pixels;
     float kernel_ms;           /* HIP-event time of the render kernel(s), 0 if not measured */
     uint64_t lens_steps;       /* RK4 steps taken by the lens extension (0 when it is off) */
-    uint32_t slices;           /* S of the last launch: workgroups own 256/S pixels and deal their samples to the lanes
-                                * through a queue (1 = a lane owns a pixel and all of its samples); DESIGN.md 5.3 */
+    uint32_t slices;           /* S of the last launch: pixel blocks of 256/S pixels whose samples are dealt to the lanes of a
+                                * workgroup through a queue; DESIGN.md 5.3 */
     uint32_t launches;         /* kernel launches the render was split into (deep renders under the scratch cap) */
-    uint64_t scratch_bytes;    /* HBM the handle holds for parked sample values after this render (0: none needed) */
-    uint64_t parked_bytes;     /* bytes of sample values the render parked in HBM (0 when they stayed in LDS / registers) */
+    uint64_t scratch_bytes;    /* HBM the handle holds for parked sample values after this render */
+    uint64_t parked_bytes;     /* bytes of sample values the render parked in HBM (12 per sample, edge tiles padded) */
+    uint32_t queue;            /* 1 = block queue (a workgroup per pixel block, which it sums itself); 2 = flow queue */
+    uint32_t reserved;
 } bt_stats;
 
 /* Launch-shape knobs of a scene handle.  Every field's zero / negative value means "let the library decide" (what
  * bt_tuning_default() fills in); the library itself never reads environment variables.  Tests and the A/B tools under
  * tools/ set these to pin a shape; none of them can change a pixel (tests/test_gpu_parity.py renders every setting). */
 typedef struct {
-    uint32_t slices;           /* 0 = auto; 1, 2, 4, 8, 16, 32: pixel blocks of 256 / slices pixels (streaming queue: >= 4) */
-    uint32_t tiles_per_wg;     /* 0 = auto; 1, 2, 4: whole tiles per workgroup for shallow launches (2 and 4 imply slices = 1) */
-    int32_t queue;             /* -1 = auto; 0 = a lane owns a pixel (no parked samples); 1 = block queue (a workgroup per pixel
-                                * block; what auto picks, since round 2 also for one ray per pixel); 2 = streaming queue (persistent
-                                * workgroups claim pixel blocks and park sample values in a small ring, in LDS when it fits) */
-    int32_t phase_vote;        /* -1 = auto; 0 = off; n = longest wait in iterations (sphere-only builds) */
-    int32_t kernel_variant;    /* BT_KERNEL_DEFAULT / _LANES / _SORTED, per handle */
-    int32_t park;              /* streaming queue: -1 = auto; 0 = the ring of parked sample values in HBM scratch; 1 = in LDS */
-    uint64_t scratch_cap_bytes;/* block queue: 0 = default (2 GiB); deeper renders are split into several launches */
-    uint32_t workgroups_per_cu;/* streaming queue: 0 = auto; persistent workgroups launched per CU (1 .. 8) */
-    uint32_t ring_slots;       /* streaming queue: 0 = auto; 2 or 4 parking slots per workgroup */
+    uint32_t slices;           /* 0 = auto; 1, 2, 4, 8, 16, 32: pixel blocks of 256 / slices pixels */
+    int32_t queue;             /* -1 = auto; 1 = block queue: workgroup b owns pixel block b, deals its (pixel, sample) pairs to its
+                                * lanes and adds the parked sample values to the frame itself; 2 = flow queue: a few persistent
+                                * workgroups per CU claim block after block (no wait for a block's slowest path), a second kernel
+                                * does the ordered sums -- what auto picks for launches that park little (Output::Full without the
+                                * lens extension only; any other render runs the block queue) */
+    int32_t phase_vote;        /* -1 = auto; 0 = off; n = longest wait of the phase vote in iterations */
+    uint32_t workgroups_per_cu;/* flow queue: 0 = auto; persistent workgroups launched per CU (1 .. 8) */
+    uint64_t scratch_cap_bytes;/* 0 = the default 2 GiB: most parked sample values per launch; deeper renders are split into
+                                * several launches over consecutive sample ranges */
 } bt_tuning;
 
 /* EXTENSION -- NOT IN THE REFERENCE.  bendy-tracer v1 traces straight rays only (`Ray::at` is
@@ -224,15 +225,6 @@ void bt_tuning_default(bt_tuning *out);
 /* NULL restores the defaults.  Returns BT_ERR_INVALID_ARG for a value outside the sets above. */
 int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *tuning);
 int bt_scene_get_tuning(const bt_scene *scene, bt_tuning *out);
-
-/* Two bit-identical implementations of the render kernel exist:
- * BT_KERNEL_LANES  -- path state in registers; a workgroup owns a block of pixels and deals their samples to its lanes
- *                     through an LDS work queue (default, fastest measured; a lane owns a pixel only on request,
- *                     bt_tuning.queue = 0, or when no scratch memory can be had);
- * BT_KERNEL_SORTED -- path state in LDS, the workgroup re-sorts its 256 paths by pending event kind
- *                     every iteration (ballot / prefix-sum compaction).  Selected per scene handle through
- *                     bt_tuning.kernel_variant; BT_KERNEL_DEFAULT is the built-in choice (LANES). */
-enum { BT_KERNEL_DEFAULT = 0, BT_KERNEL_LANES = 1, BT_KERNEL_SORTED = 2 };
 
 /* Returns the device memory a handle keeps between calls -- the parked sample values of the work queue (bt_stats.scratch_bytes;
  * it otherwise shrinks only after eight consecutive renders that needed less than a quarter of it) and bt_render's cached copy

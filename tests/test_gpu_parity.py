@@ -243,17 +243,19 @@ def test_sliced_render_matches_oracle(bendy, oracle, name, w, h, spp, n, output)
     assert np.array_equal(buf.numpy(), it)
 
 
+@pytest.mark.parametrize("queue", [1, 2])
 @pytest.mark.parametrize("slices", [1, 2, 4, 8, 16, 32])
-def test_every_slice_count_gives_the_same_frame(bendy, oracle, slices):
+def test_every_slice_count_gives_the_same_frame(bendy, oracle, slices, queue):
     """bt_tuning.slices forces S: each block shape (16x16 ... 4x2 pixels) must give the oracle's bits, on a ragged
-    frame, in the full-frame and in the sharded layout."""
+    frame, in the full-frame and in the sharded layout -- with the block queue (a workgroup per block, which sums it) and
+    with the flow queue (persistent workgroups claim blocks, bt_sum_parked_kernel sums)."""
     import torch
     w, h, spp, world = 70, 41, 24, 3
-    buf, stats, _ = gpu_render(bendy, "cornell", w, h, spp, tuning={"slices": slices})
-    assert stats.slices == slices
+    buf, stats, _ = gpu_render(bendy, "cornell", w, h, spp, tuning={"slices": slices, "queue": queue})
+    assert stats.slices == slices and stats.queue == queue
     it, seg = oracle_render(oracle, "cornell", w, h, spp)
     assert stats.segments == seg and np.array_equal(buf.numpy(), it)
-    sc, cam = gpu_scene(bendy, "cornell", w, h, tuning={"slices": slices})
+    sc, cam = gpu_scene(bendy, "cornell", w, h, tuning={"slices": slices, "queue": queue})
     tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
     shards = [_render_shard(bendy, tr, sc, cam, w, h, spp, r, world) for r in range(world)]
     out = bendy.Buffer.new(w, h)
@@ -262,39 +264,61 @@ def test_every_slice_count_gives_the_same_frame(bendy, oracle, slices):
     assert np.array_equal(out.numpy(), it)
 
 
-@pytest.mark.parametrize("tiles", [1, 2, 4])
+@pytest.mark.parametrize("queue", [1, 2])
 @pytest.mark.parametrize("world", [1, 3])
-def test_several_tiles_per_workgroup(bendy, oracle, tiles, world):
-    """Shallow launches give a workgroup 2 or 4 whole tiles (BtLaunch::tiles_per_wg; bt_tuning.tiles_per_wg forces it):
-    ragged frame, an odd number of tiles, full-frame and sharded layout, the interactive pattern (1 sample x Subpixel(2))."""
+@pytest.mark.parametrize("name,samples,n", [("cornell2", 1, 2), ("scene", 1, 0), ("volume", 3, 0)])
+def test_shallow_launches_on_both_queues(bendy, oracle, name, samples, n, world, queue):
+    """The reference's interactive pattern (main.rs:245-254: one Tracer::render of 1 sample x Subpixel(2) per displayed frame)
+    and one ray per pixel: ragged frame, an odd number of tiles, full-frame and sharded layout.  Auto picks the flow queue
+    for these; both queues must give the oracle's bits."""
     import torch
     w, h = 150, 75                                   # 10 x 5 tiles, ragged right / bottom edge
-    it, _ = oracle_render(oracle, "cornell2", w, h, 1, n=2)
-    sc, cam = gpu_scene(bendy, "cornell2", w, h, tuning={"tiles_per_wg": tiles, "slices": 1})    # whole tiles: S = 1
+    it, seg = oracle_render(oracle, name, w, h, samples, n=n)
+    sc, cam = gpu_scene(bendy, name, w, h, tuning={"queue": queue})
     tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
-    rc = bendy.RenderConfig.with_samples_subsample(1, bendy.Subsample(2))
+    rc = bendy.RenderConfig.with_samples_subsample(samples, bendy.Subsample(n))
     if world == 1:
         buf = bendy.Buffer.new(w, h)
         tr.render(sc, cam, rc, buf)
         torch.cuda.synchronize()
-        assert sc.last_stats().slices == 1 and np.array_equal(buf.numpy(), it)
-        grid = 50
+        st = sc.last_stats()
+        assert st.queue == queue and st.segments == seg and np.array_equal(buf.numpy(), it)
+        auto, st_auto, _ = gpu_render(bendy, name, w, h, samples, n=n)
+        assert st_auto.queue == 2 and np.array_equal(auto.numpy(), it)
     else:
         shards = []
         for r in range(world):
             s = bendy.new_shard(w, h, world)
             tr.render_shard(sc, cam, rc, s, w, h, r, world)
             shards.append(s)
-        grid = -(-50 // world)
-    # the last workgroup's parking slots exist even when the tile count is not a multiple of tiles_per_wg (150 x 75 has 50
-    # tiles, 17 per rank at world 3): highest index written = workgroups * 256 * tiles * T parked values of 12 bytes
-    workgroups, T = -(-grid // tiles), 4
-    assert sc.last_stats().scratch_bytes >= workgroups * tiles * 256 * T * 12
-    if world != 1:
         out = bendy.Buffer.new(w, h)
         bendy.unshard(torch.cat(shards), out, world)
         torch.cuda.synchronize()
         assert np.array_equal(out.numpy(), it)
+
+
+def test_flow_queue_progressive_prefilled_and_more_blocks_than_workgroups(bendy, oracle):
+    """Flow queue: (1) progressive calls into a prefilled buffer add up like the block queue's (`*r += pixel.r`,
+    buffer.rs:159-164); (2) a frame with many more pixel blocks than persistent workgroups (every workgroup walks several
+    blocks; bt_tuning.workgroups_per_cu = 1 makes that 30 blocks each) and one with fewer blocks than workgroups."""
+    import torch
+    w, h = 96, 64
+    sc, cam = gpu_scene(bendy, "cloud", w, h, tuning={"queue": 2})
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    buf = bendy.Buffer.new(w, h)
+    for i in range(5):
+        tr.render(sc, cam, bendy.RenderConfig.with_samples(3), buf)
+    torch.cuda.synchronize()
+    it, _ = oracle_render(oracle, "cloud", w, h, 15)
+    assert buf.samples == 15 and sc.last_stats().queue == 2 and np.array_equal(buf.numpy(), it)
+    w, h = 1280, 720                                   # 3 600 tiles
+    ref, st1, _ = gpu_render(bendy, "cornell2", w, h, 2, tuning={"queue": 1})
+    for wpc, slices in ((1, 2), (0, 0), (8, 1)):
+        got, st, _ = gpu_render(bendy, "cornell2", w, h, 2, tuning={"queue": 2, "workgroups_per_cu": wpc, "slices": slices})
+        assert st.queue == 2 and st.segments == st1.segments and np.array_equal(got.numpy(), ref.numpy()), (wpc, slices)
+    small, st, _ = gpu_render(bendy, "scene", 40, 24, 2, tuning={"queue": 2})          # 6 blocks
+    it, seg = oracle_render(oracle, "scene", 40, 24, 2)
+    assert st.segments == seg and np.array_equal(small.numpy(), it)
 
 
 @pytest.mark.parametrize("max_wait", [0, 1, 2, 7])
@@ -536,100 +560,19 @@ def test_density_map_larger_than_the_lds_budget(bendy, oracle):
         _compare_json_scene(bendy, oracle, random_scene(seed, n_objects=6, volume_prob=1.0, density_dims=(24,)), 64, 40, 4)
 
 
-# ---- the regrouping kernel (bt_kernels_sorted.hip) is bit-identical to the default one ---------------------
-@pytest.fixture
-def sorted_kernel():
-    """bt_tuning.kernel_variant is per scene handle: the tests pass this to gpu_render / gpu_scene."""
-    return {"kernel_variant": "sorted"}
+# ---- both queues at full size -----------------------------------------------------------------------------------------
+def test_both_queues_at_full_size(bendy, oracle):
+    """BASELINE configs[1] (cornell2 512 x 512 x 16 spp) whole against the oracle on both queues; a 1080p frame at 4 samples
+    (16 320 pixel blocks over 1 792 persistent workgroups) and C3 at 64 samples: flow queue == block queue, bit for bit."""
+    it, seg = oracle_render(oracle, "cornell2", 512, 512, 16, threads=_host_threads())
+    for queue in (1, 2):
+        buf, st, _ = gpu_render(bendy, "cornell2", 512, 512, 16, tuning={"queue": queue})
+        assert st.queue == queue and st.segments == seg and np.array_equal(buf.numpy(), it), queue
+    for name, spp in (("volume", 4), ("scene", 64)):
+        a, sa, _ = gpu_render(bendy, name, 1920, 1080, spp, tuning={"queue": 1})
+        b_, sb, _ = gpu_render(bendy, name, 1920, 1080, spp, tuning={"queue": 2})
+        assert sa.queue == 1 and sb.queue == 2 and sa.segments == sb.segments and np.array_equal(a.numpy(), b_.numpy()), name
 
-
-@pytest.mark.parametrize("case", sorted(_golden_cases()))
-def test_sorted_kernel_matches_golden(bendy, sorted_kernel, case):
-    name, w, h, spp, n, out = _golden_cases()[case]
-    g = np.load(os.path.join(GOLDEN, case + ".npz"))
-    buf, stats, _ = gpu_render(bendy, name, w, h, spp, n=n, output=out, tuning=sorted_kernel)
-    assert stats.segments == int(g["segments"]) and np.array_equal(buf.numpy(), g["iterative"])
-
-
-@pytest.mark.parametrize("seed", [0, 3, 5, 9, 13, 17, 18, 19, 22])
-def test_sorted_kernel_random_scenes(bendy, oracle, sorted_kernel, seed):
-    test_random_scenes_bit_exact(bendy, oracle, seed, tuning=sorted_kernel)
-
-
-def test_sorted_kernel_full_size_equals_default(bendy, sorted_kernel):
-    a, sa, _ = gpu_render(bendy, "scene", 1920, 1080, 64, tuning=sorted_kernel)
-    c, sc_, _ = gpu_render(bendy, "cloud", 480, 270, 16, tuning=sorted_kernel)
-    b_, sb, _ = gpu_render(bendy, "scene", 1920, 1080, 64, tuning={"kernel_variant": "lanes"})
-    d, sd, _ = gpu_render(bendy, "cloud", 480, 270, 16, tuning={"kernel_variant": "lanes"})
-    assert sa.segments == sb.segments and np.array_equal(a.numpy(), b_.numpy())
-    assert sc_.segments == sd.segments and np.array_equal(c.numpy(), d.numpy())
-
-
-def test_scene_tables_beyond_64kb_of_lds(bendy, oracle):
-    """700 objects (~2000 table rows, ~100 KB of per-lane lookup tables): the launch raises the kernel's dynamic
-    LDS limit (gfx950: 160 KB per CU) instead of failing at the default 64 KB."""
-    from scene_gen import random_scene
-    gs = _compare_json_scene(bendy, oracle, random_scene(11, n_objects=700, n_lights=(3, 3)), 48, 32, 2)
-    assert gs.export_prims().shape[0] > 1800          # x 32 B of BtPrimLite alone is > 57 KB
-
-
-def test_many_objects(bendy, oracle):
-    from scene_gen import random_scene
-    gs = _compare_json_scene(bendy, oracle, random_scene(7, n_objects=60, n_lights=(4, 4)), 64, 40, 2)
-    assert gs.export_prims().shape[0] > 100
-
-
-# ---- the streaming queue (bt_tuning.queue = 2): persistent workgroups claim pixel blocks, ring of parked units ------
-@pytest.mark.parametrize("park", [0, 1])
-@pytest.mark.parametrize("name,w,h,spp,n,output,slices", [
-    ("scene", 96, 54, 24, 0, 0, 0), ("cornell", 70, 41, 24, 0, 0, 32), ("cloud", 200, 120, 37, 0, 0, 0),
-    ("volume", 96, 64, 16, 0, 0, 8), ("cornell2", 150, 75, 3, 2, 0, 4), ("scene", 320, 180, 64, 0, 0, 16),
-    ("scene", 64, 48, 8, 0, 1, 0), ("cornell", 64, 48, 8, 0, 2, 0), ("volume", 64, 48, 8, 0, 3, 4)])
-def test_streaming_queue_matches_oracle(bendy, oracle, name, w, h, spp, n, output, slices, park):
-    """Same bits as the oracle (and therefore as the block queue) for ragged frames, every block size, chunked units,
-    odd sample counts, Subpixel(2), every Output -- with the ring of parked values in LDS and in HBM."""
-    tuning = {"queue": 2, "park": park, "slices": slices}
-    buf, stats, _ = gpu_render(bendy, name, w, h, spp, n=n, output=output, tuning=tuning)
-    it, seg = oracle_render(oracle, name, w, h, spp, n=n, output=output)
-    assert stats.segments == seg and np.array_equal(buf.numpy(), it)
-    # the ring is a few MB at most, never the 16 B per sample of the block queue
-    assert stats.scratch_bytes <= 256 * 8 * 4 * 1024 * 16
-
-
-def test_streaming_queue_progressive_sharded_and_prefilled(bendy, oracle):
-    """Progressive calls into a pre-filled buffer (main.rs:245-254) and the sharded layout (3 ranks, ragged) through the
-    streaming queue."""
-    import torch
-    w, h, world = 70, 41, 3
-    tuning = {"queue": 2}
-    sc, cam = gpu_scene(bendy, "cornell", w, h, tuning=tuning)
-    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
-    buf = bendy.Buffer.new(w, h)
-    for _ in range(3):
-        tr.render(sc, cam, bendy.RenderConfig.with_samples(8), buf)
-    it, _ = oracle_render(oracle, "cornell", w, h, 24)
-    assert buf.samples == 24 and np.array_equal(buf.numpy(), it)
-    shards = []
-    for r in range(world):
-        s = bendy.new_shard(w, h, world)
-        tr.render_shard(sc, cam, bendy.RenderConfig.with_samples(24), s, w, h, r, world)
-        shards.append(s)
-    out = bendy.Buffer.new(w, h)
-    bendy.unshard(torch.cat(shards), out, world)
-    torch.cuda.synchronize()
-    assert np.array_equal(out.numpy(), it)
-
-
-def test_streaming_queue_full_size_equals_block_queue(bendy):
-    """C3 and C4 at full size: the streaming queue (ring in LDS / in HBM) gives the block queue's frame bit for bit, with
-    no scratch (LDS) or a ring of ~100 MB (HBM) instead of 2 GB."""
-    for name in ("scene", "volume"):
-        a, sa, _ = gpu_render(bendy, name, 1920, 1080, 64, tuning={"queue": 1})
-        assert sa.parked_bytes >= 1920 * 1080 * 64 * 12                   # 12 B per sample (edge tiles padded)
-        for park in (1, 0):
-            b_, sb, _ = gpu_render(bendy, name, 1920, 1080, 64, tuning={"queue": 2, "park": park})
-            assert sb.segments == sa.segments and np.array_equal(a.numpy(), b_.numpy())
-            assert sb.scratch_bytes == 0 if sb.parked_bytes == 0 else sb.scratch_bytes < 256 * 1024 * 1024
 
 
 # ---- the exchange step behind the C ABI (bt_comm_*): RCCL at world 1 on the single GPU ------------------------------

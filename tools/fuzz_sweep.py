@@ -27,8 +27,8 @@ for seed in range(first, first + n):
     w, h, spp = 96 + 16 * (seed % 3), 64 + 8 * (seed % 4), 3 + seed % 6
     out = seed % 4
     gs = bendy.Scene.from_json(txt); cam = gs.find_by_tag("camera"); gs.set_camera_aspect(cam, w / h)
-    if seed % 5 == 0:
-        gs.set_tuning(queue=2)                      # the streaming queue on every fifth scene
+    if seed % 2 == 0:
+        gs.set_tuning(queue=1)                      # auto picks the flow queue for frames this small: every other scene on the block queue
     buf = bendy.Buffer.new(w, h)
     bendy.Tracer.with_config(bendy.Config(output=bendy.Output(out))).render(gs, cam, bendy.RenderConfig.with_samples(spp), buf, seed=seed)
     torch.cuda.synchronize()

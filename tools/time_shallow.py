@@ -1,29 +1,34 @@
-"""Developer tool: shallow launches (T = 1, 2, 4, 8 rays per pixel per call) on a 1080p frame under tiles-per-workgroup /
-slices / lanes settings -- the data behind bt_api.cpp's choice for the interactive pattern (main.rs:245-254)."""
+"""Developer tool: launches of T = 1 ... 64 rays per pixel per call on a frame (BT_FRAME, default 1920x1080) under both work
+queues and several pixel-block sizes -- the data behind bt_api.cpp's choice of queue and block size (the reference's
+interactive pattern, main.rs:245-254, is T = 1 sample x Subpixel(2) = 4).  Prints ms per pipelined call (wall) and the
+kernels' HIP-event time; modes: q1 = block queue (auto S), q2 = flow queue (auto S), q2:sN = flow queue with 256/N-pixel blocks."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
 import bendy_tracer_amd as b
 w, h = (int(x) for x in os.environ.get('BT_FRAME', '1920x1080').split('x'))
 names = os.environ.get('BT_ONLY', 'scene,cornell2,volume').split(',')
+shapes = [(1, 1), (2, 1), (1, 2), (8, 1), (16, 1), (32, 1), (64, 1)]
+if os.environ.get('BT_T'):
+    shapes = [(int(t), 1) if t != '4' else (1, 2) for t in os.environ['BT_T'].split(',')]
+modes = os.environ.get('BT_MODES', 'auto,q1,q2,q2:s1,q2:s2,q2:s4,q2:s8,q2:s16').split(',')
 for name in names:
     sc = b.Scene.load(f'scenes/{name}.json.gz'); cam = sc.find_by_tag('camera'); sc.set_camera_aspect(cam, w / h)
     tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
-    for samples, sub in ((1, 1), (2, 1), (1, 2), (8, 1), (16, 1), (32, 1), (128, 1)):
+    for samples, sub in shapes:
         row = []
-        for mode in ('auto', 't1', 't2', 's2', 's4', 's8', 's16', 'lanes'):
+        for mode in modes:
             sc.set_tuning()
-            if mode == 'lanes':
-                sc.set_tuning(queue=0)
-            elif mode[0] == 't':
-                sc.set_tuning(tiles_per_wg=int(mode[1:]), slices=1)
-            elif mode[0] == 's':
-                sc.set_tuning(slices=int(mode[1:]))
+            if mode != 'auto':
+                q, _, s_ = mode.partition(':')
+                sc.set_tuning(queue=int(q[1:]), slices=int(s_[1:]) if s_ else 0)
             buf = b.Buffer.new(w, h)
             rc = b.RenderConfig.with_samples_subsample(samples, b.Subsample(sub))
             try:
-                for i in range(3):
+                ks = []
+                for i in range(4):
                     tr.render(sc, cam, rc, buf)
+                    ks.append(sc.last_stats().kernel_ms)
                 torch.cuda.synchronize()
                 t = time.perf_counter()
                 n = 30
@@ -32,7 +37,7 @@ for name in names:
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t) / n
                 st = sc.last_stats()
-                row.append(f'{mode}:{dt*1e3:.3f}({st.slices})')
+                row.append(f'{mode}:{dt*1e3:.3f}/k{min(ks[1:]):.3f}(q{st.queue} S{st.slices})')
             except Exception as e:
-                row.append(f'{mode}:err')
-        print(f'{name:9s} T={samples*sub*sub:3d} ms per call  ' + '  '.join(row), flush=True)
+                row.append(f'{mode}:err {str(e)[:40]}')
+        print(f'{name:9s} {w}x{h} T={samples*sub*sub:3d} ms per call  ' + '  '.join(row), flush=True)

@@ -1,4 +1,4 @@
-"""Times the BASELINE workloads on the GPU (developer tool).  BT_SLICES / BT_QUEUE / BT_PHASE_VOTE / BT_PARK / ... in the
+"""Times the BASELINE workloads on the GPU (developer tool).  BT_SLICES / BT_QUEUE / BT_PHASE_VOTE / ... in the
 environment are turned into bt_tuning fields here (Scene.tuning_from_env); the library does not read them."""
 import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
