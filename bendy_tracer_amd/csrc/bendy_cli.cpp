@@ -175,8 +175,8 @@ int main(int argc, char **argv) {
         auto env = [&](const char *name, auto &field) {
             if (const char *e = std::getenv(name)) { field = (std::remove_reference_t<decltype(field)>)std::strtoll(e, nullptr, 10); any = true; }
         };
-        env("BT_SLICES", t.slices); env("BT_QUEUE", t.queue); env("BT_PHASE_VOTE", t.phase_vote);
-        env("BT_SCRATCH_CAP", t.scratch_cap_bytes); env("BT_WGS_PER_CU", t.workgroups_per_cu);
+        env("BT_SLICES", t.slices); env("BT_PHASE_VOTE", t.phase_vote); env("BT_END_GAME", t.end_game);
+        env("BT_MARCH_POOL", t.march_pool); env("BT_MARCH_ENTER", t.march_enter); env("BT_SCRATCH_CAP", t.scratch_cap_bytes);
         if (any) check(bt_scene_set_tuning(scene, &t), "bt_scene_set_tuning");
     }
 
@@ -222,9 +222,9 @@ int main(int argc, char **argv) {
             bt_stats cs{};
             bt_scene_last_stats(scene, &cs);
             char row[256];
-            std::snprintf(row, sizeof row, "%s{\"kernel_ms\": %.5f, \"segments\": %llu, \"samples\": %llu, \"pixels\": %llu, \"slices\": %u, \"queue\": %u}",
+            std::snprintf(row, sizeof row, "%s{\"kernel_ms\": %.5f, \"segments\": %llu, \"samples\": %llu, \"pixels\": %llu, \"slices\": %u, \"pool_records\": %u}",
                           per_call.empty() ? "" : ", ", cs.kernel_ms, (unsigned long long)cs.segments,
-                          (unsigned long long)cs.samples, (unsigned long long)cs.pixels, cs.slices, cs.queue);
+                          (unsigned long long)cs.samples, (unsigned long long)cs.pixels, cs.slices, cs.pool_records);
             per_call += row;
         }
         if (!args.quiet)

@@ -32,9 +32,11 @@ thread_local std::string g_error;
 thread_local int g_error_code = 0;
 constexpr uint64_t kDefaultScratchCap = 2ull << 30;   // parked sample values per launch; deeper renders are split
 constexpr uint32_t kScratchShrinkAfter = 8;           // renders in a row that need < 1/4 of the scratch before it shrinks
-constexpr uint64_t kFlowMaxParkedBytes = 128ull << 20; // launches that park at most this much run the flow queue (+ its sum kernel)
-constexpr uint32_t kFlowBlockItems = 512;             // work items of a flow-queue pixel block (>= 256: the kernel's cursor logic)
-constexpr uint32_t kFlowWorkgroupsPerCu = 7;          // persistent workgroups per CU = what __launch_bounds__(256, 7) keeps resident
+// The path pool (bt_kernels.hip): defaults measured in round 3 (profiles/r04c)
+constexpr int32_t kEndGamePushMax = 16;               // a wave down to this many live paths at the end of a block hands them over
+constexpr int32_t kMarchPoolRecords = 128;            // march stack (scenes with volumes), when the LDS budget allows
+constexpr int32_t kMarchEnter = 32;                   // records that make a wave take the march role
+constexpr size_t kLdsPerWorkgroup7 = (160 * 1024) / 7 - 128;   // dynamic LDS a workgroup may use with seven workgroups per CU
 int set_error(int code, const std::string &msg) {
     g_error = msg;
     g_error_code = code;
@@ -385,7 +387,6 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     uint32_t chunk = (uint32_t)P.samples;                         // samples per launch
     P.slices = 1;
     P.scratch = nullptr;
-    P.flow = 0;
     P.table_lds_bytes = (uint32_t)s->flat.lds_bytes();
     size_t lds_bytes = s->flat.lds_bytes();
     {
@@ -438,18 +439,10 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         chunk = (chunk + 1) / 2;
     }
     P.scratch = s->d_scratch;
-    // Flow queue: shallow launches of Output::Full without the lens.  A block queue workgroup ends with a
-    // drain -- lanes that find the queue empty wait for the workgroup's slowest path -- which costs little at 16 samples per
-    // lane and a quarter of the lane slots at 4; persistent workgroups that claim block after block drain once per launch.
-    // What it costs is a second kernel for the ordered sums, which re-reads the parked values: worth it while those are few.
-    int queue = tune.queue >= 1 ? tune.queue : 1;      // measured (profiles/r04b): the flow queue loses on shallow launches, ties on C2
-    if (output != 0 || P.lens_on) queue = 1;
     auto pick = [&](uint64_t T) -> uint32_t {
         if (tune.slices) return tune.slices;
         uint32_t S = 1;
-        if (queue == 2) {
-            while (S < 32 && 256 * T / (2 * S) >= kFlowBlockItems) S *= 2;    // blocks of ~kFlowBlockItems work items, at least 256
-        } else if (P.lens_on) {
+        if (P.lens_on) {
             while (S < 32 && T / (2 * S) >= 4) S *= 2;       // lens paths differ far more in length: ~4 samples per lane
         } else {
             // Measured on 1080p and 512 x 512 frames, T = 1 ... 128 rays per pixel per launch, and on the shards of 2 / 4 / 8
@@ -471,14 +464,35 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         const uint64_t longest = ((uint64_t)P.max_bounces + 2) * ((uint64_t)P.max_volume_bounces + 3) + (P.lens_on ? 2 : 0);
         const uint64_t items_max = std::max<uint64_t>(1, 0xffffffffull / longest);
         const uint64_t pxb = 256u / (uint32_t)P.slices;
-        if (queue != 2 && pxb * chunk * nn > items_max) chunk = (uint32_t)std::max<uint64_t>(1, items_max / (pxb * nn));
+        if (pxb * chunk * nn > items_max) chunk = (uint32_t)std::max<uint64_t>(1, items_max / (pxb * nn));
     }
-    P.n_blocks = grid * (uint32_t)P.slices;
-    if (queue == 2) {
-        const uint32_t wpc = tune.workgroups_per_cu ? tune.workgroups_per_cu : kFlowWorkgroupsPerCu;
-        P.flow = 1;
-        P.flow_grid = std::min<uint32_t>(P.n_blocks, (uint32_t)s->n_cu * wpc);
-        P.block_counter = (uint32_t *)(s->d_counters + BT_BLOCK_COUNTER_SLOT);
+    {
+        // The path pool: end-game stack for every render without the lens (3 waves x pool_push_max records), march stack for
+        // scenes with volumes, sized so that seven workgroups per CU still fit their LDS (cloud.json's 16 KB density map leaves
+        // room for a small one only)
+        const size_t entry = (output == 0 ? 20 : 28) * 4;
+        P.pool_lds_offset = (uint32_t)((lds_bytes + 15) & ~(size_t)15);
+        P.pool_push_max = P.lens_on ? 0 : (tune.end_game >= 0 ? tune.end_game : kEndGamePushMax);
+        P.pool_e_cap = 3 * P.pool_push_max;
+        size_t used = P.pool_lds_offset + (size_t)P.pool_e_cap * entry;
+        int32_t m_cap = 0;
+        if (!P.lens_on && P.vbox_lds_bytes) {          // some sphere carries a volume (and the tables are small enough for the boxes)
+            m_cap = tune.march_pool >= 0 ? tune.march_pool : kMarchPoolRecords;
+            if (tune.march_pool < 0 && used + (size_t)m_cap * entry > kLdsPerWorkgroup7)
+                m_cap = used < kLdsPerWorkgroup7 ? (int32_t)((kLdsPerWorkgroup7 - used) / entry) : 0;
+            if (m_cap < 24) m_cap = 0;                  // not worth a role
+        }
+        P.pool_m_cap = m_cap;
+        P.pool_m_enter = tune.march_enter >= 0 ? tune.march_enter : std::min(kMarchEnter, std::max(1, m_cap / 2));
+        if (P.pool_e_cap + P.pool_m_cap > 0) lds_bytes = used + (size_t)P.pool_m_cap * entry;
+    }
+    {
+        // watchdog bounds (BtLaunch::max_handouts / max_dry_iters)
+        const uint64_t longest = ((uint64_t)P.max_bounces + 3) * ((uint64_t)P.max_volume_bounces + 4) *
+                                 (P.lens_on ? 2 + (uint64_t)P.lens_max_steps / 8 : 1);
+        const uint64_t items = (256u / (uint32_t)P.slices) * (uint64_t)chunk * nn;
+        P.max_handouts = (uint32_t)std::min<uint64_t>(items + 1024, 0xfffffff0u);
+        P.max_dry_iters = (uint32_t)std::min<uint64_t>(4 * (longest * 6 + 1024), 0xfffffff0u);
     }
     const uint64_t parked_bytes = px_launch * T_all * 3 * sizeof(float);
 
@@ -499,7 +513,6 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         for (uint32_t done = 0; done < all; done += chunk) {
             P.samples = (int32_t)std::min(chunk, all - done);
             P.sample_base = base + done;
-            if (P.flow) BT_HIP(hipMemsetAsync(P.block_counter, 0, sizeof(unsigned long long), stream));
             BT_HIP(bt_launch_render(&P, output, grid, lds_bytes, stream));
             launches += 1;
         }
@@ -521,7 +534,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     s->last.segments = 0;
     s->last.kernel_ms = 0.0f;
     s->last.slices = (uint32_t)P.slices;
-    s->last.queue = P.flow ? 2u : 1u;
+    s->last.pool_records = (uint32_t)(P.pool_e_cap + P.pool_m_cap);
     s->last.launches = launches;
     s->last.scratch_bytes = s->scratch_bytes;
     s->last.parked_bytes = parked_bytes;
@@ -558,8 +571,10 @@ int bt_last_error_code(void) { return g_error_code; }
 void bt_tuning_default(bt_tuning *t) {
     if (!t) return;
     std::memset(t, 0, sizeof *t);
-    t->queue = -1;
     t->phase_vote = -1;
+    t->end_game = -1;
+    t->march_pool = -1;
+    t->march_enter = -1;
 }
 
 int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
@@ -571,10 +586,9 @@ int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
     const uint32_t S = t->slices;
     if (!(S == 0 || S == 1 || S == 2 || S == 4 || S == 8 || S == 16 || S == 32))
         return set_error(BT_ERR_INVALID_ARG, "bt_tuning.slices must be 0 (auto), 1, 2, 4, 8, 16 or 32");
-    if (t->workgroups_per_cu > 8)
-        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.workgroups_per_cu must be 0 .. 8");
-    if (!(t->queue == -1 || t->queue == 1 || t->queue == 2) || t->phase_vote < -1 || t->phase_vote > 64)
-        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.queue must be -1 (auto), 1 (block queue) or 2 (flow queue), phase_vote -1 .. 64");
+    if (t->phase_vote < -1 || t->phase_vote > 64 || t->end_game < -1 || t->end_game > 64 || t->march_pool < -1 || t->march_pool > 1024 ||
+        t->march_enter < -1 || t->march_enter > 1024)
+        return set_error(BT_ERR_INVALID_ARG, "bt_tuning: phase_vote and end_game must be -1 .. 64, march_pool and march_enter -1 .. 1024");
     scene->tuning = *t;
     return 0;
 }
@@ -842,6 +856,13 @@ int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {
 #endif
         float ms = 0.0f;
         BT_HIP(hipEventElapsedTime(&ms, scene->ev_start, scene->ev_stop));
+        if (c[BT_WATCHDOG_SLOT] != 0) {
+            scene->stats_pending = false;
+            char msg[160];
+            std::snprintf(msg, sizeof msg, "render loop watchdog fired (%s, workgroup %llu): the frame of the last render is incomplete",
+                          (c[BT_WATCHDOG_SLOT] >> 32) == 1 ? "work-queue hand-outs" : "end-game iterations", c[BT_WATCHDOG_SLOT] & 0xffffffffull);
+            return set_error(BT_ERR_DEVICE, msg);
+        }
         scene->last.segments = c[0];
         scene->last.lens_steps = c[1];
         scene->last.kernel_ms = ms;

@@ -13,10 +13,10 @@
 //     their samples in this launch.  The block's (pixel, sample) pairs are a work queue in LDS: a lane whose path has
 //     ended takes the next pair, every sample's value is parked in HBM and the last wave of the workgroup adds the
 //     parked values to the frame in sample order -- the reference's per-pixel summation order, no atomics on the frame;
-//   * flow queue (shallow launches, BtLaunch::flow): the launch is a few persistent workgroups per CU that CLAIM pixel
-//     blocks from a counter in HBM and deal each block's pairs the same way, but a lane flows on into the workgroup's
-//     next block instead of waiting for the block's slowest path; the ordered sums are a second, tiny kernel
-//     (bt_sum_parked_kernel) over the parked values;
+//   * paths can change lanes through a small pool in LDS (72-byte records under a workgroup spin lock): at the end of a
+//     block the waves that are down to a few live paths hand them to the waves that still have many and leave (end-game
+//     compaction), and in scenes with volumes a path that enters a volume is handed to a wave that does nothing but march
+//     (march pool) -- scheduling only, every path performs the same operations in the same order;
 //   * in the sphere-only builds a wave votes every iteration whether it runs the camera event or the scatter / volume
 //     events; the lanes of the other kind keep their state for the next iteration (phase voting);
 //   * every loop iteration is TRACE (one path segment, all lanes) followed by exactly ONE random event per lane --
@@ -64,6 +64,10 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 BT_DEV uint32_t lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+// a word of the workgroup's LDS state, read / written as such (ds_read_b32 / ds_write_b32; a volatile generic pointer would
+// make it a flat access)
+BT_DEV uint32_t lds_get(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+BT_DEV void lds_set(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // the lanes that execute THIS instruction: EXEC read in place (a `__ballot(true)` is an expression the optimizer may
 // evaluate earlier, where lanes that have since left for the loop head still count)
 BT_DEV unsigned long long exec_here() {
@@ -216,25 +220,23 @@ BT_DEV void sum_block(const BtLaunch &P, const BlockGeom &g, uint32_t b, uint32_
 #endif
 // RECTS = false: sphere-only scenes (scene.json, volume.json, cloud.json) run a build without any rect / cuboid code.
 // VOLS = false: no sphere carries a volume (scene.json, the Cornell boxes): the march and Volume::shade drop out.
-// FLOW = true: the flow queue (persistent workgroups claim pixel blocks; OUTPUT = Full without the lens only).
-template <int OUTPUT, bool LENS, bool RECTS, bool VOLS, bool FLOW>
+template <int OUTPUT, bool LENS, bool RECTS, bool VOLS>
 __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : (VOLS ? BT_WAVES_PER_SIMD_VOLS : BT_WAVES_PER_SIMD))) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_waves_done;      // block queue: waves of this workgroup that have parked all their samples
     __shared__ uint32_t s_next_item;       // the workgroup's work queue (next unclaimed (pixel, sample) pair)
     __shared__ uint32_t s_segments;        // path segments traced by this workgroup
-    __shared__ uint32_t s_blk[4];          // flow queue: the pixel block (launch order) behind this workgroup's n-th block, n mod 4
-    __shared__ uint32_t s_nclaimed;        // flow queue: blocks claimed so far (s_blk[n & 3] is valid for n < s_nclaimed)
+    __shared__ uint32_t s_pool_lock;       // path pool: spin lock of this workgroup's waves (0 = free)
+    __shared__ uint32_t s_running;         // path pool: waves that have not left the render loop yet
+    __shared__ uint32_t s_cnt_e, s_cnt_m;  // path pool: records in the end-game stack / in the march stack
     if (threadIdx.x == 0) {
         s_waves_done = 0;
         s_next_item = 0;
         s_segments = 0;
-        if (FLOW) {                        // the first two blocks of this workgroup's walk (0xffffffff: the launch has none left)
-            const uint32_t b0 = atomicAdd(P.block_counter, 1u), b1 = b0 < P.n_blocks ? atomicAdd(P.block_counter, 1u) : b0;
-            s_blk[0] = b0 < P.n_blocks ? b0 : 0xffffffffu;
-            s_blk[1] = b1 < P.n_blocks ? b1 : 0xffffffffu;
-            s_nclaimed = 2;
-        }
+        s_pool_lock = 0;
+        s_running = blockDim.x >> 6;
+        s_cnt_e = 0;
+        s_cnt_m = 0;
     }
 
     // ---- stage the per-lane lookup tables in LDS ----
@@ -303,12 +305,12 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     const uint32_t sample0 = P.sample_base * nn;
     const uint32_t n_items = pxb * T;                  // work items of one block
     // block queue: this workgroup's one block (launch order = blockIdx.x)
-    const BlockRef B_own = block_ref(P, G, FLOW ? 0u : blockIdx.x);
+    const BlockRef B_own = block_ref(P, G, blockIdx.x);
 
     // the lane's current work item: pixel_index keys the Philox counter; park_i = the item's number i = k * pxb + pixel in
-    // its block, where its value is parked (block queue: + the workgroup's base; the sample number k comes out of it, one
-    // register less than keeping both -- flow queue: + block * n_items, and k travels in k_cur)
-    uint32_t px = 0, py = 0, pixel_index = 0, park_i = 0, k_cur = 0;
+    // the block, where its value is parked (+ the workgroup's base; the sample number k comes out of it, one register less
+    // than keeping both)
+    uint32_t px = 0, py = 0, pixel_index = 0, park_i = 0;
     bool alive = true;                                 // until the workgroup's queue is empty (see the loop)
 
     // per-lane path state
@@ -321,6 +323,8 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     bool pending = true;               // the lane has no ray yet: its next event is the camera ray
     // phase voting (BtLaunch::phase_vote): a lane whose scatter event lost the vote keeps its hit for the next iteration
     constexpr bool VOTE = !RECTS && !LENS;    // pays where the events, not TRACE, are most of an iteration
+    constexpr bool POOL = !LENS;              // paths may change lanes through the LDS pool (a bent lens segment has too much state)
+    constexpr bool HELD = VOTE || (POOL && VOLS);   // a lane may carry a hit into its next iteration (vote loser, march-pool record)
     bool held = false;
     float held_t = 0.0f;
     int held_info = 0, waited = 0;     // held_info = prim | inside << 29 | p_neg << 30
@@ -345,41 +349,83 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         } else {
             value = first;
         }
-        if (FLOW) ((Parked *)P.scratch)[park_i] = Parked{value.x, value.y, value.z};
-        else ((Parked *)P.scratch + (size_t)blockIdx.x * n_items)[park_i] = Parked{value.x, value.y, value.z};
+        ((Parked *)P.scratch + (size_t)blockIdx.x * n_items)[park_i] = Parked{value.x, value.y, value.z};
     };
 
-    // ---- flow queue (BtLaunch::flow): persistent workgroups that claim pixel blocks -------------------------------------
-    // The launch is gridDim.x workgroups (a few per CU); each claims blocks one ahead of its need from a counter in HBM,
-    // so the blocks go to whoever is free.  The workgroup's items are its blocks' items back to back -- ONE counter in
-    // LDS hands them out, so a lane that has finished a sample flows on into the next block without the drain at the end
-    // of every block that the block queue pays (28 % of all lane slots on the 512 x 512 Cornell box,
-    // profiles/r02d/lanestat_block_queue.log).  Nothing is summed here: every value is parked at
-    // scratch[block * n_items + i] and bt_sum_parked_kernel adds them up afterwards.
-    // The wave's cursor: the block (sequence number n in this workgroup's walk) that holds the items it was handed last.
-    uint32_t u_n = 0, u_start = 0;                     // wave-uniform
-    uint32_t b_cur = 0xffffffffu, b_nxt = 0xffffffffu; // the cursor's block and the one after it (launch order; 0xffffffff: none)
-    if (FLOW) __syncthreads();                         // s_blk[0], s_blk[1] of the prologue
-    // Makes sure this workgroup's n-th block has been claimed (wave-uniform; called when the cursor enters block n - 1,
-    // so the claim -- one global atomic, a microsecond -- is long done when a lane needs it).  s_blk holds the last four.
-    auto ensure_claimed = [&](uint32_t n) {
-        const int first_lane = __ffsll((long long)exec_here()) - 1;
-        if ((int)lane == first_lane) {
-            // one wave at a time moves s_nclaimed from n to n + 1: compare-and-swap through a "claiming" marker in the top bit
-            for (;;) {
-                const uint32_t nc = __hip_atomic_load(&s_nclaimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((nc & 0x7fffffffu) > n) break;                                     // claimed (by this or another wave)
-                if (nc == n && atomicCAS(&s_nclaimed, n, n | 0x80000000u) == n) {
-                    const uint32_t b = atomicAdd(P.block_counter, 1u);
-                    __hip_atomic_store(&s_blk[n & 3u], b < P.n_blocks ? b : 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    BT_LDS_FENCE();
-                    __hip_atomic_store(&s_nclaimed, n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);                                           // another wave is claiming block n
-            }
-        }
+    // ---- the path pool ----------------------------------------------------------------------------------------------------
+    // A path between two loop iterations is 18 dwords (ray, throughput, radiance, its work item, counters, a hit it may be
+    // holding; 23 with the AOV registers).  Records of ENTRY_DW dwords live in dynamic LDS behind the scene tables, in two
+    // stacks under ONE spin lock per workgroup (four waves contend; the holder never waits for anything else):
+    //   * the END-GAME stack (every build without the lens).  When the block's queue has run dry a workgroup used to drain:
+    //     every wave kept issuing for its last few long paths (4.6 % of all lane slots on C3, 10 % on C4, 28 % on C2,
+    //     profiles/r02d/lanestat_block_queue.log).  Now a wave that is down to <= pool_push_max live paths pushes them and
+    //     leaves the loop; the idle lanes of the waves that stay pop them.  The last running wave never pushes, and a wave
+    //     leaves empty-handed only when both stacks are empty -- checked under the lock, so no record is ever stranded.
+    //   * the MARCH stack (scenes with volumes).  A path whose hit is the front face of a volume is pushed, with the hit, by a
+    //     wave in the SURFACE role, which then hands the lane its next camera sample; a wave in the MARCH role fills its idle
+    //     lanes from this stack only -- its instruction stream is try_hit_volume + Volume::shade, no camera, Diffuse or
+    //     light-pdf blocks (mod.rs:344-373, 404-427, 488-523; volume.rs:26-60).  A wave takes the march role when the stack
+    //     holds pool_m_enter records and gives it up when more than half of its lanes find the stack empty; a full stack
+    //     simply means the path marches where it is.
+    // Scheduling only: a record is restored bit for bit, Philox is keyed by (pixel, sample, event), the parked value goes
+    // to the item's own slot -- every path performs the same operations in the same order on whichever lane it sits.
+    constexpr uint32_t ENTRY_DW = OUTPUT == 0 ? 20u : 28u;      // (25 used in the AOV builds)
+    uint32_t *const pool_e = (uint32_t *)(smem + P.pool_lds_offset);
+    uint32_t *const pool_m = pool_e + P.pool_e_cap * ENTRY_DW;
+    // Two facts about the WAVE steer all of this: `dry` (the block's queue has no items left) and `march_role`.  They must be
+    // wave-uniform -- a hand-out whose leader lane sat in another branch would deal the same items again, for ever -- but
+    // they are learnt by whichever lanes stand at the hand-out.  So every lane carries a copy (dry_l, march_l), and the top
+    // of the loop, where all lanes of the wave meet, turns the copies into one ballot-derived value per iteration.
+    bool dry_l = false, march_l = false;
+    // Watchdog: a scheduling bug must end in an error code, never in a hung GPU.  Two wave-uniform counters at decisions the
+    // loop takes anyway: hand-outs of the work queue (more than the block has items: the queue is declared dry) and iterations
+    // of the end-game (more than the longest path can need: the wave leaves).  Both report through counters[BT_WATCHDOG_SLOT].
+    uint32_t n_handouts = 0, n_dry_iters = 0;
+    auto pool_lock = [&]() {           // (the holder never waits for anything: a critical section is a few dozen LDS accesses)
+        const int fl = __ffsll((long long)exec_here()) - 1;
+        if ((int)lane == fl)
+            while (atomicCAS(&s_pool_lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
         BT_LDS_FENCE();
+    };
+    auto pool_unlock = [&]() {
+        BT_LDS_FENCE();
+        const int fl = __ffsll((long long)exec_here()) - 1;
+        if ((int)lane == fl) __hip_atomic_store(&s_pool_lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // A record is written and read one dword at a time, straight out of / into the registers that hold the path (volatile
+    // address-space-3 accesses: ds_write_b32 / ds_read_b32 with immediate offsets).  Packing it into 128-bit accesses needs
+    // twenty more registers at a point of the loop where everything else is live -- the allocator then spills in the hot
+    // blocks (seen: 60 -> 72 VGPRs + scratch in the C3 build); a record moves once per path and end of block, its cost is nothing.
+    typedef volatile __attribute__((address_space(3))) uint32_t LdsWord;
+    typedef volatile __attribute__((address_space(3))) float LdsFloat;
+    auto store_path = [&](uint32_t *e, bool with_hit, float hit_t, int hit_info) {
+        LdsFloat *f = (LdsFloat *)e;
+        LdsWord *w = (LdsWord *)e;
+        f[0] = ro.x; f[1] = ro.y; f[2] = ro.z; f[3] = rd.x; f[4] = rd.y; f[5] = rd.z;
+        f[6] = beta.x; f[7] = beta.y; f[8] = beta.z; f[9] = L.x; f[10] = L.y; f[11] = L.z;
+        w[12] = park_i; w[13] = pixel_index; w[14] = event; w[15] = (uint32_t)bounce;
+        w[16] = (uint32_t)vbounce; w[17] = (uint32_t)last_object; f[18] = hit_t;
+        w[19] = ((uint32_t)hit_info & 0x7fffffffu) | (with_hit ? 0x80000000u : 0u);
+        if (OUTPUT != 0) {
+            f[20] = first.x; f[21] = first.y; f[22] = first.z; f[23] = first_depth; w[24] = have_first ? 1u : 0u;
+        }
+    };
+    auto load_path = [&](const uint32_t *e) {
+        LdsFloat *f = (LdsFloat *)e;
+        LdsWord *w = (LdsWord *)e;
+        ro.x = f[0]; ro.y = f[1]; ro.z = f[2]; rd.x = f[3]; rd.y = f[4]; rd.z = f[5];
+        beta.x = f[6]; beta.y = f[7]; beta.z = f[8]; L.x = f[9]; L.y = f[10]; L.z = f[11];
+        park_i = w[12]; pixel_index = w[13]; event = w[14]; bounce = (int)w[15];
+        vbounce = (int)w[16]; last_object = (int)w[17];
+        held_t = f[18];
+        const uint32_t info = w[19];
+        held = HELD && (info >> 31) != 0u;
+        held_info = (int)(info & 0x7fffffffu);
+        if (OUTPUT != 0) {
+            first.x = f[20]; first.y = f[21]; first.z = f[22]; first_depth = f[23]; have_first = w[24] != 0u;
+        }
+        pending = false;
+        waited = 0;
     };
 
     BT_PROF_DECL;
@@ -400,8 +446,68 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         V3 prim_c = mk(0, 0, 0);
         float prim_radius = 0.0f;
         int hit_prim = 0;
+        bool want_push = false;                         // (VOLS) this lane's path goes to the march stack
 
-        BT_LS(1, __ballot(!pending && !(VOTE && held)));
+        // ---- the wave's facts for this iteration (all of its lanes in the loop are here) ----
+        const bool dry = POOL && __ballot(dry_l) != 0ull;
+        bool march_role = POOL && VOLS && __ballot(march_l) != 0ull;
+        dry_l = dry;
+        // ---- idle lanes look for a path in the pool: every wave once the block's queue has run dry, a march-role wave always ----
+        if (POOL && (dry || march_role)) {                            // wave-uniform
+            const unsigned long long act = exec_here(), m_free = __ballot(pending);
+            const uint32_t n_free = popc64(m_free), n_live = popc64(act) - n_free;
+            bool leave = false;
+            // (the counts are peeked at without the lock: a stale value costs one more look in the next iteration)
+            const uint32_t peek = lds_get(&s_cnt_e) + (VOLS ? lds_get(&s_cnt_m) : 0u);
+            if (dry) n_dry_iters = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_dry_iters) + 1u;     // (wave-uniform: lives in an SGPR)
+            if (dry && n_dry_iters > P.max_dry_iters) {                       // watchdog
+                if ((int)lane == __ffsll((long long)act) - 1 && P.counters) atomicMax(&P.counters[BT_WATCHDOG_SLOT], (2ull << 32) | blockIdx.x);
+                leave = true;
+            } else if ((n_free && peek) || (dry && n_live <= (uint32_t)P.pool_push_max)) {
+                pool_lock();
+                const uint32_t ce = lds_get(&s_cnt_e), cm = VOLS ? lds_get(&s_cnt_m) : 0u;
+                const uint32_t running = lds_get(&s_running);
+                const uint32_t from_m = dry ? cm : (cm < n_free ? cm : n_free);      // a march-role wave before the end-game: march stack only
+                const uint32_t avail = (dry ? ce : 0u) + from_m;
+                const int fl = __ffsll((long long)act) - 1;
+                if (n_free && avail) {
+                    // pop: idle lane number r takes the r-th record from the top, march stack first
+                    const uint32_t r = lanes_below(m_free), take_m = from_m < n_free ? from_m : n_free;
+                    const uint32_t take_e = dry ? (ce < n_free - take_m ? ce : n_free - take_m) : 0u;
+                    if (pending && r < take_m) load_path(pool_m + (cm - 1u - r) * ENTRY_DW);
+                    else if (pending && r < take_m + take_e) load_path(pool_e + (ce - 1u - (r - take_m)) * ENTRY_DW);
+                    BT_LDS_FENCE();                                           // the records are read before the counts move
+                    if ((int)lane == fl) {
+                        if (VOLS) lds_set(&s_cnt_m, cm - take_m);
+                        if (take_e) lds_set(&s_cnt_e, ce - take_e);
+                    }
+                } else if (dry && n_live == 0) {
+                    // no path, nothing to pop: this wave is done (both stacks are empty, and whoever pushes later stays)
+                    if ((int)lane == fl) lds_set(&s_running, running - 1u);
+                    leave = true;
+                } else if (dry && n_live <= (uint32_t)P.pool_push_max && running > 1u && ce + n_live <= (uint32_t)P.pool_e_cap) {
+                    // end-game: hand the last few paths to the waves that stay, and leave
+                    const uint32_t r = lanes_below(act & ~m_free);
+                    if (!pending) store_path(pool_e + (ce + r) * ENTRY_DW, HELD && held, held_t, held_info);
+                    if ((int)lane == fl) {
+                        lds_set(&s_cnt_e, ce + n_live);
+                        lds_set(&s_running, running - 1u);
+                    }
+                    leave = true;
+                }
+                pool_unlock();
+            }
+            if (leave) break;                                                 // wave-uniform
+            if (march_role && !dry) {
+                // a march-role wave more than half of whose lanes found the stack empty goes back to camera samples
+                const uint32_t still_idle = popc64(__ballot(pending));
+                if (still_idle > 32u) march_role = false;
+            }
+            if (pending && (dry || march_role)) { march_l = march_role; continue; }   // idle lane
+        }
+        march_l = march_role;
+
+        BT_LS(1, __ballot(!pending && !(HELD && held)));
         if (!pending) {
             // ---- TRACE: try_hit (mod.rs:389-402) / try_hit_volume (mod.rs:404-427) ----
             const bool marching = VOLS && last_object >= 0;
@@ -424,7 +530,8 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 bent = false;
                 captured = r < 0;
                 travelled = lens.travelled;
-            } else if (VOTE && held) {                // the hit found one iteration ago (phase voting)
+            } else if (HELD && held) {                // the hit found earlier: by this lane one iteration ago (phase voting), or
+                                                      // by the lane that pushed the path into the march stack
                 h.t = held_t;
                 h.prim = held_info & 0x1fffffff;
                 h.inside = (held_info >> 29) & 1;
@@ -485,7 +592,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     // sample_surface (mod.rs:454-486): emitted, then Material::shade
                     mat_index = pl.material;
                     const BtMaterial &M = S.materials[mat_index];
-                    if (!(VOTE && held)) L = L + beta * mk(M.emitted);
+                    if (!(HELD && held)) L = L + beta * mk(M.emitted);
                     if (M.kind == BT_MAT_DIFFUSE) ev = EV_DIFFUSE;
                     else if (M.kind == BT_MAT_METALLIC) ev = EV_METALLIC;
                     else if (M.kind == BT_MAT_GLASS) ev = EV_GLASS;
@@ -500,12 +607,30 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 }
             }
             if (ended) finish_sample();
-            if (VOTE && P.phase_vote && ev != EV_GEN) {       // in case this lane's event loses the vote below
+            if (HELD && ev != EV_GEN) {               // in case this lane's event loses the vote below, or its path changes lanes
                 held_t = h.t;
                 held_info = h.prim | ((int)h.inside << 29) | ((int)h.p_neg << 30);
             }
+            // a path that enters a volume (front face, not marching yet) goes to the march stack when this wave is in the
+            // surface role: the lane is free for its next camera sample
+            if (VOLS && POOL) want_push = ev == EV_VOLUME && !marching && !held && !march_role && !dry && P.pool_m_cap > 0;
         }
         pending = false;
+        if (VOLS && POOL && P.pool_m_cap) {
+            const unsigned long long m_push = __ballot(want_push);
+            if (m_push) {                                                     // wave-uniform
+                pool_lock();
+                const uint32_t cm = lds_get(&s_cnt_m), r = lanes_below(m_push), n_push = popc64(m_push);
+                const bool ok = want_push && cm + r < (uint32_t)P.pool_m_cap;
+                if (ok) store_path(pool_m + (cm + r) * ENTRY_DW, true, held_t, held_info);
+                const uint32_t cm_new = cm + n_push < (uint32_t)P.pool_m_cap ? cm + n_push : (uint32_t)P.pool_m_cap;
+                if ((int)lane == __ffsll((long long)m_push) - 1) lds_set(&s_cnt_m, cm_new);
+                pool_unlock();
+                if (ok) ev = EV_GEN;                                          // (a full stack: the path marches where it is)
+            }
+        }
+        if (HELD && !(VOTE && P.phase_vote)) held = false;                    // the hit a record brought along has been used (the
+                                                                              // vote, where it runs, settles `held` itself)
 
         if (VOTE && P.phase_vote) {
             // ---- which events run this iteration?  The kind more lanes want (camera | scatter / volume step); nobody waits
@@ -535,52 +660,48 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         // ---- a lane whose path has ended (or that has none yet) moves on to its next sample ----
         {
             const unsigned long long need = __ballot(ev == EV_GEN);
-            if (need) {                                                   // one LDS atomic for the whole wave
+            if (need && !dry && !march_role) {                            // one LDS atomic for the whole wave (both flags are wave-uniform)
                 const int leader = __ffsll((long long)need) - 1;
-                uint32_t base = 0;
-                if ((int)lane == leader) base = atomicAdd(&s_next_item, (uint32_t)__popcll(need));
+                const uint32_t n_need = popc64(need);
+                uint32_t base = 0, cm_peek = 0;
+                if ((int)lane == leader) {
+                    if (VOLS && POOL) cm_peek = lds_get(&s_cnt_m);
+                    base = atomicAdd(&s_next_item, n_need);
+                }
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                if (FLOW) {
-                    // move the wave's cursor to the block that holds `base`; the block after it was claimed when the cursor
-                    // entered this one (a block holds >= 256 items: the wave's 64 items lie in the cursor's block or the next)
-                    while (base >= u_start + n_items) {
-                        u_start += n_items;
-                        u_n += 1u;
-                        ensure_claimed(u_n + 1u);
-                    }
-                    b_cur = __hip_atomic_load(&s_blk[u_n & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    b_nxt = __hip_atomic_load(&s_blk[(u_n + 1u) & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                n_handouts = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_handouts) + 1u;
+                if (n_handouts > P.max_handouts) {                        // watchdog: this wave has been dealt more often than the block has items
+                    if ((int)lane == leader && P.counters) atomicMax(&P.counters[BT_WATCHDOG_SLOT], (1ull << 32) | blockIdx.x);
+                    base = n_items;
+                }
+                if (POOL && base + n_need > n_items) dry_l = true;        // the queue is exhausted (with this hand-out or before):
+                                                                          // the whole wave knows from the next iteration on
+                if (VOLS && POOL) {
+                    // enough paths wait in the march stack for a wave of their own: this one takes the role.  The items of this
+                    // hand-out are still rendered here; from the next iteration on its idle lanes pop marching paths instead
+                    cm_peek = (uint32_t)__builtin_amdgcn_readlane((int)cm_peek, leader);
+                    if (cm_peek >= (uint32_t)P.pool_m_enter && P.pool_m_cap > 0) march_l = true;
                 }
                 if (ev == EV_GEN) {
-                    uint32_t i = base + lanes_below(need);
-                    BlockRef B = B_own;
-                    if (FLOW) {
-                        i -= u_start;
-                        const bool nxt = i >= n_items;
-                        if (nxt) i -= n_items;
-                        const uint32_t b = nxt ? b_nxt : b_cur;
-                        if (b == 0xffffffffu) break;                      // the launch has no blocks left: this lane is done
-                        // the two blocks' places in the frame are wave-uniform (scalar); the lane picks its own
-                        const BlockRef Bc = block_ref(P, G, b_cur == 0xffffffffu ? 0u : b_cur), Bn = block_ref(P, G, b_nxt == 0xffffffffu ? 0u : b_nxt);
-                        B.px0 = nxt ? Bn.px0 : Bc.px0;
-                        B.py0 = nxt ? Bn.py0 : Bc.py0;
-                        B.tile_ok = nxt ? Bn.tile_ok : Bc.tile_ok;
-                        B.slot = nxt ? Bn.slot : Bc.slot;
-                        park_i = b * n_items + i;
-                    } else {
-                        if (i >= n_items) break;                          // the block's samples are all taken
-                        park_i = i;                                       // (+ the workgroup's base, see finish_sample)
+                    const uint32_t i = base + lanes_below(need);
+                    if (i >= n_items) {                                   // the block's samples are all taken
+                        if (!POOL) break;
+                        pending = true;                                   // idle: looks into the pool at the top of the loop
+                        continue;
                     }
-                    const PixelRef r = pixel_of(P, G, B, i & (pxb - 1u));
+                    park_i = i;                                           // (+ the workgroup's base, see finish_sample)
+                    const PixelRef r = pixel_of(P, G, B_own, i & (pxb - 1u));
                     px = r.px;
                     py = r.py;
-                    if (FLOW) k_cur = i >> LOG_PXB;
                     if (!r.in_frame) {
                         pending = true;                                   // pixel outside the frame (edge tile): skip it
                         continue;
                     }
                     pixel_index = py * P.width + px;
                 }
+            } else if (need && ev == EV_GEN) {
+                pending = true;                                           // dry, or a march-role wave: this lane looks into the pool at
+                continue;                                                 // the top of the loop
             }
         }
         BT_PROF(1);                                       // TRACE + hit classification
@@ -589,7 +710,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         BT_LS(5, __ballot(ev == EV_GLASS)); BT_LS(6, __ballot(ev == EV_VOLUME));
         // ---- the lane's one random event of this iteration (numerics contract N6) ----
         // block queue: the item's sample number comes out of its item number (one register less than keeping both)
-        const uint32_t k_now = FLOW ? k_cur : park_i >> LOG_PXB;
+        const uint32_t k_now = park_i >> LOG_PXB;
         const uint32_t sample_index = sample0 + k_now;
         const U4 u = philox(pixel_index, sample_index, ev == EV_GEN ? 0u : event, 0u, P.seed_lo, P.seed_hi);
         // slots of the two angular draws: Metallic [0],[1]; Glass [1],[2]; everything else [2],[3]
@@ -797,8 +918,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     // ---- the end of a workgroup --------------------------------------------------------------------------------------
     // Block queue: the last wave of the workgroup to get here performs `*r += pixel.r` (buffer.rs:159-164) for every parked
     // sample of the block's pixels, in sample order (sum_block).  The parked values were written by waves of this
-    // workgroup (same CU, same L1 / L2), so workgroup-scope release / acquire is all the ordering that is needed.  Flow
-    // queue: bt_sum_parked_kernel does the sums after this kernel; the last wave only reports the segment count.
+    // workgroup (same CU, same L1 / L2), so workgroup-scope release / acquire is all the ordering that is needed.
     if (P.counters) {
         uint32_t sg = segments;
 #pragma unroll
@@ -815,7 +935,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             const uint32_t total = *(volatile uint32_t *)&s_segments;
             if (total) atomicAdd(&P.counters[0], (unsigned long long)total);
         }
-        if (!FLOW) sum_block(P, G, blockIdx.x, T, (const Parked *)P.scratch + (size_t)blockIdx.x * n_items, lane);
+        sum_block(P, G, blockIdx.x, T, (const Parked *)P.scratch + (size_t)blockIdx.x * n_items, lane);
     }
     if (P.counters) {
         if (LENS) {
@@ -836,13 +956,6 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             for (int i = 0; i < BT_N_COUNTERS - 2; ++i) atomicAdd(&P.counters[2 + i], prof_acc[i]);
 #endif
     }
-}
-
-// Flow queue, second kernel: the ordered per-pixel sums over the parked values (sum_block), one wave per pixel block.
-__global__ __launch_bounds__(64) void bt_sum_parked_kernel(BtLaunch P) {
-    const BlockGeom G = block_geom(P);
-    const uint32_t T = (uint32_t)P.samples * (uint32_t)(P.subsample_n * P.subsample_n);
-    sum_block(P, G, blockIdx.x, T, (const Parked *)P.scratch + (size_t)blockIdx.x * G.pxb * T, threadIdx.x);
 }
 
 // shard (tile-major, `world` ranks back to back) -> row-major frame; rgb AND alpha copied.
@@ -921,39 +1034,31 @@ __global__ __launch_bounds__(256) void bt_preview_kernel(const float4 *rgba, uin
 // ---- host-side launchers (called from bt_api.cpp) ---------------------------------------------
 extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream) {
-    // block queue: grid = tiles to render, a tile is P->slices workgroups (see the mapping in the kernel); flow queue:
-    // P->flow_grid persistent workgroups, then one wave per pixel block for the ordered sums
-    dim3 g(P->flow ? P->flow_grid : grid * (unsigned)P->slices), b(256);
+    // grid = tiles to render; a tile is P->slices workgroups (see the mapping in the kernel)
+    dim3 g(grid * (unsigned)P->slices), b(256);
     // scene classes: bit 0 = some sphere carries a volume (volume.json, cloud.json), bit 1 = rects / cuboids present
     // (the Cornell boxes); scene.json is class 0
     const int cls = (P->any_rects ? 2 : 0) | (P->any_volumes ? 1 : 0);
     // scene tables beyond the default 64 KB of dynamic LDS (hundreds of objects): gfx950 has 160 KB per CU, the limit
     // has to be raised per kernel; one workgroup per CU is then all that fits
-#define BT_LAUNCH(O, L, R, V, F)                                                                                 \
+#define BT_LAUNCH(O, L, R, V)                                                                                    \
     do {                                                                                                         \
         if (lds_bytes > 48 * 1024)                                                                               \
-            (void)hipFuncSetAttribute((const void *)bt_render_kernel<O, L, R, V, F>,                             \
+            (void)hipFuncSetAttribute((const void *)bt_render_kernel<O, L, R, V>,                                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
-        hipLaunchKernelGGL((bt_render_kernel<O, L, R, V, F>), g, b, lds_bytes, stream, *P);                      \
+        hipLaunchKernelGGL((bt_render_kernel<O, L, R, V>), g, b, lds_bytes, stream, *P);                         \
     } while (0)
 #define BT_LAUNCH_OUT(L, R, V)                                                                                   \
     switch (output) {                                                                                            \
-    case 0: BT_LAUNCH(0, L, R, V, false); break;                                                                 \
-    case 1: BT_LAUNCH(1, L, R, V, false); break;                                                                 \
-    case 2: BT_LAUNCH(2, L, R, V, false); break;                                                                 \
-    default: BT_LAUNCH(3, L, R, V, false); break;                                                                \
+    case 0: BT_LAUNCH(0, L, R, V); break;                                                                        \
+    case 1: BT_LAUNCH(1, L, R, V); break;                                                                        \
+    case 2: BT_LAUNCH(2, L, R, V); break;                                                                        \
+    default: BT_LAUNCH(3, L, R, V); break;                                                                       \
     }
 #define BT_LAUNCH_CLASS(L)                                                                                       \
     if (cls == 3) { BT_LAUNCH_OUT(L, true, true) } else if (cls == 2) { BT_LAUNCH_OUT(L, true, false) }            \
     else if (cls == 1) { BT_LAUNCH_OUT(L, false, true) } else { BT_LAUNCH_OUT(L, false, false) }
-    if (P->flow) {                                  // Output::Full without the lens (bt_api.cpp asks for nothing else)
-        if (P->lens_on || output != 0) return hipErrorInvalidValue;
-        if (cls == 3) BT_LAUNCH(0, false, true, true, true); else if (cls == 2) BT_LAUNCH(0, false, true, false, true);
-        else if (cls == 1) BT_LAUNCH(0, false, false, true, true); else BT_LAUNCH(0, false, false, false, true);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(bt_sum_parked_kernel, dim3(P->n_blocks), dim3(64), 0, stream, *P);
-    } else if (P->lens_on) {
+    if (P->lens_on) {
         BT_LAUNCH_CLASS(true)
     } else {
         BT_LAUNCH_CLASS(false)

@@ -243,19 +243,17 @@ def test_sliced_render_matches_oracle(bendy, oracle, name, w, h, spp, n, output)
     assert np.array_equal(buf.numpy(), it)
 
 
-@pytest.mark.parametrize("queue", [1, 2])
 @pytest.mark.parametrize("slices", [1, 2, 4, 8, 16, 32])
-def test_every_slice_count_gives_the_same_frame(bendy, oracle, slices, queue):
+def test_every_slice_count_gives_the_same_frame(bendy, oracle, slices):
     """bt_tuning.slices forces S: each block shape (16x16 ... 4x2 pixels) must give the oracle's bits, on a ragged
-    frame, in the full-frame and in the sharded layout -- with the block queue (a workgroup per block, which sums it) and
-    with the flow queue (persistent workgroups claim blocks, bt_sum_parked_kernel sums)."""
+    frame, in the full-frame and in the sharded layout."""
     import torch
     w, h, spp, world = 70, 41, 24, 3
-    buf, stats, _ = gpu_render(bendy, "cornell", w, h, spp, tuning={"slices": slices, "queue": queue})
-    assert stats.slices == slices and stats.queue == queue
+    buf, stats, _ = gpu_render(bendy, "cornell", w, h, spp, tuning={"slices": slices})
+    assert stats.slices == slices
     it, seg = oracle_render(oracle, "cornell", w, h, spp)
     assert stats.segments == seg and np.array_equal(buf.numpy(), it)
-    sc, cam = gpu_scene(bendy, "cornell", w, h, tuning={"slices": slices, "queue": queue})
+    sc, cam = gpu_scene(bendy, "cornell", w, h, tuning={"slices": slices})
     tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
     shards = [_render_shard(bendy, tr, sc, cam, w, h, spp, r, world) for r in range(world)]
     out = bendy.Buffer.new(w, h)
@@ -264,27 +262,22 @@ def test_every_slice_count_gives_the_same_frame(bendy, oracle, slices, queue):
     assert np.array_equal(out.numpy(), it)
 
 
-@pytest.mark.parametrize("queue", [1, 2])
 @pytest.mark.parametrize("world", [1, 3])
 @pytest.mark.parametrize("name,samples,n", [("cornell2", 1, 2), ("scene", 1, 0), ("volume", 3, 0)])
-def test_shallow_launches_on_both_queues(bendy, oracle, name, samples, n, world, queue):
+def test_shallow_launches(bendy, oracle, name, samples, n, world):
     """The reference's interactive pattern (main.rs:245-254: one Tracer::render of 1 sample x Subpixel(2) per displayed frame)
-    and one ray per pixel: ragged frame, an odd number of tiles, full-frame and sharded layout.  Auto picks the flow queue
-    for these; both queues must give the oracle's bits."""
+    and one ray per pixel: ragged frame, an odd number of tiles, full-frame and sharded layout."""
     import torch
     w, h = 150, 75                                   # 10 x 5 tiles, ragged right / bottom edge
     it, seg = oracle_render(oracle, name, w, h, samples, n=n)
-    sc, cam = gpu_scene(bendy, name, w, h, tuning={"queue": queue})
+    sc, cam = gpu_scene(bendy, name, w, h)
     tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
     rc = bendy.RenderConfig.with_samples_subsample(samples, bendy.Subsample(n))
     if world == 1:
         buf = bendy.Buffer.new(w, h)
         tr.render(sc, cam, rc, buf)
         torch.cuda.synchronize()
-        st = sc.last_stats()
-        assert st.queue == queue and st.segments == seg and np.array_equal(buf.numpy(), it)
-        auto, st_auto, _ = gpu_render(bendy, name, w, h, samples, n=n)
-        assert st_auto.queue == 2 and np.array_equal(auto.numpy(), it)
+        assert sc.last_stats().segments == seg and np.array_equal(buf.numpy(), it)
     else:
         shards = []
         for r in range(world):
@@ -297,28 +290,50 @@ def test_shallow_launches_on_both_queues(bendy, oracle, name, samples, n, world,
         assert np.array_equal(out.numpy(), it)
 
 
-def test_flow_queue_progressive_prefilled_and_more_blocks_than_workgroups(bendy, oracle):
-    """Flow queue: (1) progressive calls into a prefilled buffer add up like the block queue's (`*r += pixel.r`,
-    buffer.rs:159-164); (2) a frame with many more pixel blocks than persistent workgroups (every workgroup walks several
-    blocks; bt_tuning.workgroups_per_cu = 1 makes that 30 blocks each) and one with fewer blocks than workgroups."""
-    import torch
-    w, h = 96, 64
-    sc, cam = gpu_scene(bendy, "cloud", w, h, tuning={"queue": 2})
-    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
-    buf = bendy.Buffer.new(w, h)
-    for i in range(5):
-        tr.render(sc, cam, bendy.RenderConfig.with_samples(3), buf)
-    torch.cuda.synchronize()
-    it, _ = oracle_render(oracle, "cloud", w, h, 15)
-    assert buf.samples == 15 and sc.last_stats().queue == 2 and np.array_equal(buf.numpy(), it)
-    w, h = 1280, 720                                   # 3 600 tiles
-    ref, st1, _ = gpu_render(bendy, "cornell2", w, h, 2, tuning={"queue": 1})
-    for wpc, slices in ((1, 2), (0, 0), (8, 1)):
-        got, st, _ = gpu_render(bendy, "cornell2", w, h, 2, tuning={"queue": 2, "workgroups_per_cu": wpc, "slices": slices})
-        assert st.queue == 2 and st.segments == st1.segments and np.array_equal(got.numpy(), ref.numpy()), (wpc, slices)
-    small, st, _ = gpu_render(bendy, "scene", 40, 24, 2, tuning={"queue": 2})          # 6 blocks
-    it, seg = oracle_render(oracle, "scene", 40, 24, 2)
-    assert st.segments == seg and np.array_equal(small.numpy(), it)
+# ---- the path pool: paths change lanes through LDS records (end-game compaction, march stack) -- scheduling only -------
+POOL_SETTINGS = [
+    dict(end_game=0, march_pool=0),                      # nothing ever changes lanes
+    dict(end_game=64, march_pool=0),                     # every wave but the last hands over whatever it has when the queue runs dry
+    dict(end_game=1),
+    dict(end_game=0, march_pool=24, march_enter=1),      # tiny march stack: overflows (paths march in place), roles flip constantly
+    dict(end_game=16, march_pool=512, march_enter=8),
+    dict(end_game=40, march_pool=64, march_enter=64),
+]
+
+
+@pytest.mark.parametrize("knobs", POOL_SETTINGS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+@pytest.mark.parametrize("name,w,h,spp,n,output", [
+    ("cloud", 96, 64, 12, 0, 0),
+    ("volume", 70, 41, 5, 2, 0),         # ragged, Subpixel(2)
+    ("scene", 96, 54, 24, 0, 0),         # no volumes: end-game only (vote losers carry their held hit through the pool)
+    ("cornell2", 64, 48, 9, 0, 0),       # rect build: no held hits
+    ("volume", 64, 48, 8, 0, 2),         # AOV registers travel in the record (Normal)
+    ("cloud", 48, 32, 6, 0, 3),          # ... and the first depth
+])
+def test_path_pool_is_scheduling_only(bendy, oracle, name, w, h, spp, n, output, knobs):
+    """A path's record (ray, throughput, radiance, work item, counters, held hit, AOV registers) is restored bit for bit on
+    whichever lane pops it; Philox is keyed by (pixel, sample, event) and the parked value goes to the item's own slot.
+    Every setting of the pool -- off, greedy, overflowing, flipping roles -- must give the oracle's frame and segment count."""
+    buf, stats, _ = gpu_render(bendy, name, w, h, spp, n=n, output=output, tuning=knobs)
+    it, seg = oracle_render(oracle, name, w, h, spp, n=n, output=output)
+    assert stats.segments == seg and np.array_equal(buf.numpy(), it)
+
+
+@pytest.mark.parametrize("seed", [0, 3, 5, 9, 13, 17, 18, 19, 22])
+def test_path_pool_random_scenes(bendy, oracle, seed):
+    test_random_scenes_bit_exact(bendy, oracle, seed, tuning=dict(end_game=48, march_pool=48, march_enter=4))
+
+
+def test_path_pool_with_lens_is_off(bendy):
+    """The lens extension keeps a bent segment's state per lane: its renders never use the pool."""
+    sc, cam = gpu_scene(bendy, "scene", 64, 48)
+    sc.set_lens(centre=(0.6, 0.4, 4.0), rs=0.15, step=0.25, radius=6.0, max_steps=200)
+    buf = bendy.Buffer.new(64, 48)
+    bendy.Tracer.new().render(sc, cam, bendy.RenderConfig.with_samples(2), buf)
+    assert sc.last_stats().pool_records == 0
+    sc.clear_lens()
+    bendy.Tracer.new().render(sc, cam, bendy.RenderConfig.with_samples(2), buf)
+    assert sc.last_stats().pool_records == 48
 
 
 @pytest.mark.parametrize("max_wait", [0, 1, 2, 7])
@@ -385,7 +400,7 @@ def test_render_deeper_than_the_scratch_is_split_into_launches(bendy, oracle):
     sample ranges (bt_api.cpp); bt_tuning.scratch_cap_bytes shrinks the cap so that 40 samples need 4 launches
     (12+12+12+4), pinned to the block queue."""
     w, h, spp = 64, 48, 40
-    buf, stats, _ = gpu_render(bendy, "volume", w, h, spp, tuning={"scratch_cap_bytes": 64 * 48 * 12 * 12, "queue": 1})
+    buf, stats, _ = gpu_render(bendy, "volume", w, h, spp, tuning={"scratch_cap_bytes": 64 * 48 * 12 * 12})
     it, seg = oracle_render(oracle, "volume", w, h, spp)
     assert stats.launches == 4 and 0 < stats.scratch_bytes <= 64 * 48 * 12 * 12        # 12 B per parked sample
     assert stats.slices > 1 and stats.segments == seg and stats.samples == w * h * spp
@@ -560,42 +575,18 @@ def test_density_map_larger_than_the_lds_budget(bendy, oracle):
         _compare_json_scene(bendy, oracle, random_scene(seed, n_objects=6, volume_prob=1.0, density_dims=(24,)), 64, 40, 4)
 
 
-# ---- both queues at full size -----------------------------------------------------------------------------------------
-def test_both_queues_at_full_size(bendy, oracle):
-    """BASELINE configs[1] (cornell2 512 x 512 x 16 spp) whole against the oracle on both queues; a 1080p frame at 4 samples
-    (16 320 pixel blocks over 1 792 persistent workgroups) and C3 at 64 samples: flow queue == block queue, bit for bit."""
+# ---- the path pool at full size ---------------------------------------------------------------------------------------
+def test_path_pool_at_full_size(bendy, oracle):
+    """BASELINE configs[1] (cornell2 512 x 512 x 16 spp) whole against the oracle with the pool off and on; C4's frame
+    (volume.json 1080p x 64 spp) with the pool off == the default (test_c4... compares the default with the oracle)."""
     it, seg = oracle_render(oracle, "cornell2", 512, 512, 16, threads=_host_threads())
-    for queue in (1, 2):
-        buf, st, _ = gpu_render(bendy, "cornell2", 512, 512, 16, tuning={"queue": queue})
-        assert st.queue == queue and st.segments == seg and np.array_equal(buf.numpy(), it), queue
-    for name, spp in (("volume", 4), ("scene", 64)):
-        a, sa, _ = gpu_render(bendy, name, 1920, 1080, spp, tuning={"queue": 1})
-        b_, sb, _ = gpu_render(bendy, name, 1920, 1080, spp, tuning={"queue": 2})
-        assert sa.queue == 1 and sb.queue == 2 and sa.segments == sb.segments and np.array_equal(a.numpy(), b_.numpy()), name
+    for knobs in (dict(end_game=0), dict()):
+        buf, st, _ = gpu_render(bendy, "cornell2", 512, 512, 16, tuning=knobs)
+        assert st.segments == seg and np.array_equal(buf.numpy(), it), knobs
+    a, sa, _ = gpu_render(bendy, "volume", 1920, 1080, 64, tuning=dict(end_game=0, march_pool=0))
+    b_, sb, _ = gpu_render(bendy, "volume", 1920, 1080, 64)
+    assert sa.pool_records == 0 and sb.pool_records > 48 and sa.segments == sb.segments and np.array_equal(a.numpy(), b_.numpy())
 
-
-
-# ---- the exchange step behind the C ABI (bt_comm_*): RCCL at world 1 on the single GPU ------------------------------
-def test_rccl_abi_exchange_world_1(bendy, oracle):
-    """bt_comm_unique_id / bt_comm_init / bt_exchange_frame_device (include/bendy_hip.h): ncclAllGather + un-permute
-    through the library's own run-time binding of librccl.so.1.  One rank is all a one-GPU box allows; the N > 1 layout
-    is covered on CPU (tests/test_multiproc_gloo.py) and by bench.py --backend rccl-abi on the driver's 8-GPU node."""
-    import torch
-    w, h, spp = 150, 75, 6
-    sc, cam = gpu_scene(bendy, "cornell2", w, h)
-    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
-    shard = bendy.new_shard(w, h, 1)
-    tr.render_shard(sc, cam, bendy.RenderConfig.with_samples(spp), shard, w, h, 0, 1)
-    comm = bendy.Comm(0, 1, bendy.Comm.unique_id())
-    gathered = torch.empty_like(shard)
-    out = bendy.Buffer.new(w, h)
-    comm.exchange(shard, gathered, out)
-    torch.cuda.synchronize()
-    comm.close()
-    it, _ = oracle_render(oracle, "cornell2", w, h, spp)
-    assert torch.equal(gathered, shard) and np.array_equal(out.numpy(), it)
-    with pytest.raises(bendy.BendyError):
-        bendy.Comm(3, 2, b"\0" * 128)           # rank >= world
 
 
 def test_volume_fast_paths_and_their_fallbacks(bendy, oracle):
