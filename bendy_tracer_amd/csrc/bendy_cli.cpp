@@ -176,7 +176,7 @@ int main(int argc, char **argv) {
             if (const char *e = std::getenv(name)) { field = (std::remove_reference_t<decltype(field)>)std::strtoll(e, nullptr, 10); any = true; }
         };
         env("BT_SLICES", t.slices); env("BT_PHASE_VOTE", t.phase_vote); env("BT_END_GAME", t.end_game);
-        env("BT_MARCH_POOL", t.march_pool); env("BT_MARCH_ENTER", t.march_enter); env("BT_SCRATCH_CAP", t.scratch_cap_bytes);
+        env("BT_SCRATCH_CAP", t.scratch_cap_bytes);
         if (any) check(bt_scene_set_tuning(scene, &t), "bt_scene_set_tuning");
     }
 

@@ -32,10 +32,8 @@ thread_local std::string g_error;
 thread_local int g_error_code = 0;
 constexpr uint64_t kDefaultScratchCap = 2ull << 30;   // parked sample values per launch; deeper renders are split
 constexpr uint32_t kScratchShrinkAfter = 8;           // renders in a row that need < 1/4 of the scratch before it shrinks
-// The path pool (bt_kernels.hip): defaults measured in round 3 (profiles/r04c)
-constexpr int32_t kEndGamePushMax = 16;               // a wave down to this many live paths at the end of a block hands them over
-constexpr int32_t kMarchPoolRecords = 128;            // march stack (scenes with volumes), when the LDS budget allows
-constexpr int32_t kMarchEnter = 32;                   // records that make a wave take the march role
+// End-game compaction (bt_kernels.hip "the path pool"): default measured in round 3 (profiles/r04c, r04e)
+constexpr int32_t kEndGamePushMax = 48;               // a wave down to this many live paths at the end of a block hands them over
 constexpr size_t kLdsPerWorkgroup7 = (160 * 1024) / 7 - 128;   // dynamic LDS a workgroup may use with seven workgroups per CU
 int set_error(int code, const std::string &msg) {
     g_error = msg;
@@ -467,24 +465,16 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         if (pxb * chunk * nn > items_max) chunk = (uint32_t)std::max<uint64_t>(1, items_max / (pxb * nn));
     }
     {
-        // The path pool: end-game stack for every render without the lens (3 waves x pool_push_max records), march stack for
-        // scenes with volumes, sized so that seven workgroups per CU still fit their LDS (cloud.json's 16 KB density map leaves
-        // room for a small one only)
+        // End-game compaction (scenes with rects / cuboids, without the lens: the builds that carry its code): a stack of
+        // 3 waves x pool_push_max path records, shrunk so that seven workgroups per CU still fit their LDS
         const size_t entry = (output == 0 ? 20 : 28) * 4;
         P.pool_lds_offset = (uint32_t)((lds_bytes + 15) & ~(size_t)15);
-        P.pool_push_max = P.lens_on ? 0 : (tune.end_game >= 0 ? tune.end_game : kEndGamePushMax);
-        P.pool_e_cap = 3 * P.pool_push_max;
-        size_t used = P.pool_lds_offset + (size_t)P.pool_e_cap * entry;
-        int32_t m_cap = 0;
-        if (!P.lens_on && P.vbox_lds_bytes) {          // some sphere carries a volume (and the tables are small enough for the boxes)
-            m_cap = tune.march_pool >= 0 ? tune.march_pool : kMarchPoolRecords;
-            if (tune.march_pool < 0 && used + (size_t)m_cap * entry > kLdsPerWorkgroup7)
-                m_cap = used < kLdsPerWorkgroup7 ? (int32_t)((kLdsPerWorkgroup7 - used) / entry) : 0;
-            if (m_cap < 24) m_cap = 0;                  // not worth a role
-        }
-        P.pool_m_cap = m_cap;
-        P.pool_m_enter = tune.march_enter >= 0 ? tune.march_enter : std::min(kMarchEnter, std::max(1, m_cap / 2));
-        if (P.pool_e_cap + P.pool_m_cap > 0) lds_bytes = used + (size_t)P.pool_m_cap * entry;
+        int32_t push_max = P.lens_on || !P.any_rects ? 0 : (tune.end_game >= 0 ? tune.end_game : kEndGamePushMax);
+        if (tune.end_game < 0 && P.pool_lds_offset + 3 * (size_t)push_max * entry > kLdsPerWorkgroup7)
+            push_max = P.pool_lds_offset < kLdsPerWorkgroup7 ? (int32_t)((kLdsPerWorkgroup7 - P.pool_lds_offset) / (3 * entry)) : 0;
+        P.pool_push_max = push_max;
+        P.pool_e_cap = 3 * push_max;
+        if (P.pool_e_cap > 0) lds_bytes = P.pool_lds_offset + (size_t)P.pool_e_cap * entry;
     }
     {
         // watchdog bounds (BtLaunch::max_handouts / max_dry_iters)
@@ -534,7 +524,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     s->last.segments = 0;
     s->last.kernel_ms = 0.0f;
     s->last.slices = (uint32_t)P.slices;
-    s->last.pool_records = (uint32_t)(P.pool_e_cap + P.pool_m_cap);
+    s->last.pool_records = (uint32_t)P.pool_e_cap;
     s->last.launches = launches;
     s->last.scratch_bytes = s->scratch_bytes;
     s->last.parked_bytes = parked_bytes;
@@ -573,8 +563,6 @@ void bt_tuning_default(bt_tuning *t) {
     std::memset(t, 0, sizeof *t);
     t->phase_vote = -1;
     t->end_game = -1;
-    t->march_pool = -1;
-    t->march_enter = -1;
 }
 
 int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
@@ -586,9 +574,8 @@ int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
     const uint32_t S = t->slices;
     if (!(S == 0 || S == 1 || S == 2 || S == 4 || S == 8 || S == 16 || S == 32))
         return set_error(BT_ERR_INVALID_ARG, "bt_tuning.slices must be 0 (auto), 1, 2, 4, 8, 16 or 32");
-    if (t->phase_vote < -1 || t->phase_vote > 64 || t->end_game < -1 || t->end_game > 64 || t->march_pool < -1 || t->march_pool > 1024 ||
-        t->march_enter < -1 || t->march_enter > 1024)
-        return set_error(BT_ERR_INVALID_ARG, "bt_tuning: phase_vote and end_game must be -1 .. 64, march_pool and march_enter -1 .. 1024");
+    if (t->phase_vote < -1 || t->phase_vote > 64 || t->end_game < -1 || t->end_game > 64)
+        return set_error(BT_ERR_INVALID_ARG, "bt_tuning: phase_vote and end_game must be -1 .. 64");
     scene->tuning = *t;
     return 0;
 }

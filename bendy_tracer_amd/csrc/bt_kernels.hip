@@ -15,8 +15,8 @@
 //     parked values to the frame in sample order -- the reference's per-pixel summation order, no atomics on the frame;
 //   * paths can change lanes through a small pool in LDS (72-byte records under a workgroup spin lock): at the end of a
 //     block the waves that are down to a few live paths hand them to the waves that still have many and leave (end-game
-//     compaction), and in scenes with volumes a path that enters a volume is handed to a wave that does nothing but march
-//     (march pool) -- scheduling only, every path performs the same operations in the same order;
+//     compaction; a second copy of the loop body holds all of its code) -- scheduling only, every path performs the same
+//     operations in the same order;
 //   * in the sphere-only builds a wave votes every iteration whether it runs the camera event or the scatter / volume
 //     events; the lanes of the other kind keep their state for the next iteration (phase voting);
 //   * every loop iteration is TRACE (one path segment, all lanes) followed by exactly ONE random event per lane --
@@ -215,6 +215,9 @@ BT_DEV void sum_block(const BtLaunch &P, const BlockGeom &g, uint32_t b, uint32_
 #ifndef BT_SKIP_DIR
 #define BT_SKIP_DIR 1          // a wave of pass-through march steps skips the direction sampling
 #endif
+#ifndef BT_POOL
+#define BT_POOL 1              // 0: no end-game compaction code at all (A/B knob)
+#endif
 #ifndef BT_LENS_BATCH
 #define BT_LENS_BATCH 8            // RK4 steps a lane marches per loop iteration before it yields
 #endif
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     __shared__ uint32_t s_segments;        // path segments traced by this workgroup
     __shared__ uint32_t s_pool_lock;       // path pool: spin lock of this workgroup's waves (0 = free)
     __shared__ uint32_t s_running;         // path pool: waves that have not left the render loop yet
-    __shared__ uint32_t s_cnt_e, s_cnt_m;  // path pool: records in the end-game stack / in the march stack
+    __shared__ uint32_t s_cnt_e;           // path pool: records in the end-game stack
     if (threadIdx.x == 0) {
         s_waves_done = 0;
         s_next_item = 0;
@@ -236,7 +239,6 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         s_pool_lock = 0;
         s_running = blockDim.x >> 6;
         s_cnt_e = 0;
-        s_cnt_m = 0;
     }
 
     // ---- stage the per-lane lookup tables in LDS ----
@@ -311,7 +313,6 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     // the block, where its value is parked (+ the workgroup's base; the sample number k comes out of it, one register less
     // than keeping both)
     uint32_t px = 0, py = 0, pixel_index = 0, park_i = 0;
-    bool alive = true;                                 // until the workgroup's queue is empty (see the loop)
 
     // per-lane path state
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, -1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
@@ -323,8 +324,10 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     bool pending = true;               // the lane has no ray yet: its next event is the camera ray
     // phase voting (BtLaunch::phase_vote): a lane whose scatter event lost the vote keeps its hit for the next iteration
     constexpr bool VOTE = !RECTS && !LENS;    // pays where the events, not TRACE, are most of an iteration
-    constexpr bool POOL = !LENS;              // paths may change lanes through the LDS pool (a bent lens segment has too much state)
-    constexpr bool HELD = VOTE || (POOL && VOLS);   // a lane may carry a hit into its next iteration (vote loser, march-pool record)
+    // End-game compaction (below) is compiled into the rect builds only: there it pays (C2 -11 %, Cornell -1 %); in the sphere
+    // builds its code costs the hot loop more registers than its idle lanes are worth (C3 +4 %, C4 +9 % net, as one loop or as
+    // two: profiles/r04c, r04e), and the lens extension keeps a bent segment's state per lane.
+    constexpr bool POOL = !LENS && RECTS && BT_POOL;
     bool held = false;
     float held_t = 0.0f;
     int held_info = 0, waited = 0;     // held_info = prim | inside << 29 | p_neg << 30
@@ -352,33 +355,26 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         ((Parked *)P.scratch + (size_t)blockIdx.x * n_items)[park_i] = Parked{value.x, value.y, value.z};
     };
 
-    // ---- the path pool ----------------------------------------------------------------------------------------------------
-    // A path between two loop iterations is 18 dwords (ray, throughput, radiance, its work item, counters, a hit it may be
-    // holding; 23 with the AOV registers).  Records of ENTRY_DW dwords live in dynamic LDS behind the scene tables, in two
-    // stacks under ONE spin lock per workgroup (four waves contend; the holder never waits for anything else):
-    //   * the END-GAME stack (every build without the lens).  When the block's queue has run dry a workgroup used to drain:
-    //     every wave kept issuing for its last few long paths (4.6 % of all lane slots on C3, 10 % on C4, 28 % on C2,
-    //     profiles/r02d/lanestat_block_queue.log).  Now a wave that is down to <= pool_push_max live paths pushes them and
-    //     leaves the loop; the idle lanes of the waves that stay pop them.  The last running wave never pushes, and a wave
-    //     leaves empty-handed only when both stacks are empty -- checked under the lock, so no record is ever stranded.
-    //   * the MARCH stack (scenes with volumes).  A path whose hit is the front face of a volume is pushed, with the hit, by a
-    //     wave in the SURFACE role, which then hands the lane its next camera sample; a wave in the MARCH role fills its idle
-    //     lanes from this stack only -- its instruction stream is try_hit_volume + Volume::shade, no camera, Diffuse or
-    //     light-pdf blocks (mod.rs:344-373, 404-427, 488-523; volume.rs:26-60).  A wave takes the march role when the stack
-    //     holds pool_m_enter records and gives it up when more than half of its lanes find the stack empty; a full stack
-    //     simply means the path marches where it is.
-    // Scheduling only: a record is restored bit for bit, Philox is keyed by (pixel, sample, event), the parked value goes
-    // to the item's own slot -- every path performs the same operations in the same order on whichever lane it sits.
+    // ---- end-game compaction: the path pool ---------------------------------------------------------------------------------
+    // When a block's queue has run dry a workgroup used to drain: every wave kept issuing for its last few long paths (4.6 %
+    // of all lane slots on C3, 10 % on C4, 28 % on C2, profiles/r02d/lanestat_block_queue.log).  Now a wave that is down to
+    // <= pool_push_max live paths pushes them into a stack of records in LDS and leaves; the idle lanes of the waves that stay
+    // pop them.  A path between two loop iterations is 20 dwords (ray, throughput, radiance, its work item, counters, a hit it
+    // may be holding for the phase vote; 25 with the AOV registers); the stack lives in dynamic LDS behind the scene tables,
+    // under a spin lock (four waves contend; the holder never waits for anything else).  The last running wave never pushes,
+    // and a wave leaves empty-handed only when the stack is empty -- both checked under the lock, so no record is stranded.
+    // Scheduling only: a record is restored bit for bit, Philox is keyed by (pixel, sample, event), the parked value goes to
+    // the item's own slot -- every path performs the same operations in the same order on whichever lane it sits.
+    // `dry` must be wave-uniform -- a hand-out whose leader lane sat in another branch would deal the same items again, for
+    // ever -- but it is learnt by whichever lanes stand at the hand-out.  So every lane carries a copy (dry_l), and the top of
+    // the loop, where all lanes of the wave meet, turns the copies into one ballot-derived value per iteration.
+    // (A second copy of the loop body for the end-game, so that the main loop carries none of this code, was slower on every
+    // scene: profiles/r04e.)
     constexpr uint32_t ENTRY_DW = OUTPUT == 0 ? 20u : 28u;      // (25 used in the AOV builds)
     uint32_t *const pool_e = (uint32_t *)(smem + P.pool_lds_offset);
-    uint32_t *const pool_m = pool_e + P.pool_e_cap * ENTRY_DW;
-    // Two facts about the WAVE steer all of this: `dry` (the block's queue has no items left) and `march_role`.  They must be
-    // wave-uniform -- a hand-out whose leader lane sat in another branch would deal the same items again, for ever -- but
-    // they are learnt by whichever lanes stand at the hand-out.  So every lane carries a copy (dry_l, march_l), and the top
-    // of the loop, where all lanes of the wave meet, turns the copies into one ballot-derived value per iteration.
-    bool dry_l = false, march_l = false;
+    bool dry_l = false;                // this lane has seen the queue come back short (any lane of the wave: the wave is "dry")
     // Watchdog: a scheduling bug must end in an error code, never in a hung GPU.  Two wave-uniform counters at decisions the
-    // loop takes anyway: hand-outs of the work queue (more than the block has items: the queue is declared dry) and iterations
+    // loops take anyway: hand-outs of the work queue (more than the block has items: the queue is declared dry) and iterations
     // of the end-game (more than the longest path can need: the wave leaves).  Both report through counters[BT_WATCHDOG_SLOT].
     uint32_t n_handouts = 0, n_dry_iters = 0;
     auto pool_lock = [&]() {           // (the holder never waits for anything: a critical section is a few dozen LDS accesses)
@@ -393,14 +389,11 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         if ((int)lane == fl) __hip_atomic_store(&s_pool_lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // A record is written and read one dword at a time, straight out of / into the registers that hold the path (volatile
-    // address-space-3 accesses: ds_write_b32 / ds_read_b32 with immediate offsets).  Packing it into 128-bit accesses needs
-    // twenty more registers at a point of the loop where everything else is live -- the allocator then spills in the hot
-    // blocks (seen: 60 -> 72 VGPRs + scratch in the C3 build); a record moves once per path and end of block, its cost is nothing.
+    // accesses with immediate offsets: ds_write_b32 / ds_read_b32 for the stack in LDS).  Packing it into 128-bit accesses
+    // needs twenty more registers at a point where everything else is live; a record moves once per path and end of block.
     typedef volatile __attribute__((address_space(3))) uint32_t LdsWord;
     typedef volatile __attribute__((address_space(3))) float LdsFloat;
-    auto store_path = [&](uint32_t *e, bool with_hit, float hit_t, int hit_info) {
-        LdsFloat *f = (LdsFloat *)e;
-        LdsWord *w = (LdsWord *)e;
+    auto store_path = [&](auto *f, auto *w, bool with_hit, float hit_t, int hit_info) {
         f[0] = ro.x; f[1] = ro.y; f[2] = ro.z; f[3] = rd.x; f[4] = rd.y; f[5] = rd.z;
         f[6] = beta.x; f[7] = beta.y; f[8] = beta.z; f[9] = L.x; f[10] = L.y; f[11] = L.z;
         w[12] = park_i; w[13] = pixel_index; w[14] = event; w[15] = (uint32_t)bounce;
@@ -410,20 +403,22 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             f[20] = first.x; f[21] = first.y; f[22] = first.z; f[23] = first_depth; w[24] = have_first ? 1u : 0u;
         }
     };
-    auto load_path = [&](const uint32_t *e) {
-        LdsFloat *f = (LdsFloat *)e;
-        LdsWord *w = (LdsWord *)e;
+    auto load_path = [&](auto *f, auto *w) {
         ro.x = f[0]; ro.y = f[1]; ro.z = f[2]; rd.x = f[3]; rd.y = f[4]; rd.z = f[5];
         beta.x = f[6]; beta.y = f[7]; beta.z = f[8]; L.x = f[9]; L.y = f[10]; L.z = f[11];
         park_i = w[12]; pixel_index = w[13]; event = w[14]; bounce = (int)w[15];
         vbounce = (int)w[16]; last_object = (int)w[17];
         held_t = f[18];
         const uint32_t info = w[19];
-        held = HELD && (info >> 31) != 0u;
+        held = VOTE && (info >> 31) != 0u;
         held_info = (int)(info & 0x7fffffffu);
         if (OUTPUT != 0) {
             first.x = f[20]; first.y = f[21]; first.z = f[22]; first_depth = f[23]; have_first = w[24] != 0u;
         }
+    };
+    auto push_record = [&](uint32_t slot) { store_path((LdsFloat *)(pool_e + slot * ENTRY_DW), (LdsWord *)(pool_e + slot * ENTRY_DW), VOTE && held, held_t, held_info); };
+    auto pop_record = [&](uint32_t slot) {
+        load_path((LdsFloat *)(pool_e + slot * ENTRY_DW), (LdsWord *)(pool_e + slot * ENTRY_DW));
         pending = false;
         waited = 0;
     };
@@ -433,7 +428,9 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     unsigned long long ls_acc[9] = {};
     const unsigned long long ls_all = __ballot(true);
 #endif
-    while (alive) {
+    // One loop iteration; ENDGAME (wave-uniform): the block's queue is dry, the pool code runs instead of the hand-out.
+    // Returns 0 to go on (what `continue` was), 1 when this lane -- in the end-game: this wave -- leaves the loop.
+    auto iteration = [&](const bool ENDGAME) __attribute__((always_inline)) -> int {
         BT_LS(0, 1ull);
         BT_LS(8, ls_all & ~__ballot(true));
         BT_PROF(0);                                       // loop overhead / previous iteration's tail
@@ -446,49 +443,35 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         V3 prim_c = mk(0, 0, 0);
         float prim_radius = 0.0f;
         int hit_prim = 0;
-        bool want_push = false;                         // (VOLS) this lane's path goes to the march stack
 
-        // ---- the wave's facts for this iteration (all of its lanes in the loop are here) ----
-        const bool dry = POOL && __ballot(dry_l) != 0ull;
-        bool march_role = POOL && VOLS && __ballot(march_l) != 0ull;
-        dry_l = dry;
-        // ---- idle lanes look for a path in the pool: every wave once the block's queue has run dry, a march-role wave always ----
-        if (POOL && (dry || march_role)) {                            // wave-uniform
+        if (ENDGAME) {
+            // ---- idle lanes look for a path in the pool; a wave with few paths left hands them over; an empty wave leaves ----
             const unsigned long long act = exec_here(), m_free = __ballot(pending);
             const uint32_t n_free = popc64(m_free), n_live = popc64(act) - n_free;
+            const int fl = __ffsll((long long)act) - 1;
             bool leave = false;
-            // (the counts are peeked at without the lock: a stale value costs one more look in the next iteration)
-            const uint32_t peek = lds_get(&s_cnt_e) + (VOLS ? lds_get(&s_cnt_m) : 0u);
-            if (dry) n_dry_iters = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_dry_iters) + 1u;     // (wave-uniform: lives in an SGPR)
-            if (dry && n_dry_iters > P.max_dry_iters) {                       // watchdog
-                if ((int)lane == __ffsll((long long)act) - 1 && P.counters) atomicMax(&P.counters[BT_WATCHDOG_SLOT], (2ull << 32) | blockIdx.x);
+            n_dry_iters = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_dry_iters) + 1u;     // (wave-uniform: lives in an SGPR)
+            // (the count is peeked at without the lock: a stale value costs one more look in the next iteration)
+            if (n_dry_iters > P.max_dry_iters) {                              // watchdog
+                if ((int)lane == fl && P.counters) atomicMax(&P.counters[BT_WATCHDOG_SLOT], (2ull << 32) | blockIdx.x);
                 leave = true;
-            } else if ((n_free && peek) || (dry && n_live <= (uint32_t)P.pool_push_max)) {
+            } else if ((n_free && lds_get(&s_cnt_e)) || n_live <= (uint32_t)P.pool_push_max) {
                 pool_lock();
-                const uint32_t ce = lds_get(&s_cnt_e), cm = VOLS ? lds_get(&s_cnt_m) : 0u;
-                const uint32_t running = lds_get(&s_running);
-                const uint32_t from_m = dry ? cm : (cm < n_free ? cm : n_free);      // a march-role wave before the end-game: march stack only
-                const uint32_t avail = (dry ? ce : 0u) + from_m;
-                const int fl = __ffsll((long long)act) - 1;
-                if (n_free && avail) {
-                    // pop: idle lane number r takes the r-th record from the top, march stack first
-                    const uint32_t r = lanes_below(m_free), take_m = from_m < n_free ? from_m : n_free;
-                    const uint32_t take_e = dry ? (ce < n_free - take_m ? ce : n_free - take_m) : 0u;
-                    if (pending && r < take_m) load_path(pool_m + (cm - 1u - r) * ENTRY_DW);
-                    else if (pending && r < take_m + take_e) load_path(pool_e + (ce - 1u - (r - take_m)) * ENTRY_DW);
-                    BT_LDS_FENCE();                                           // the records are read before the counts move
-                    if ((int)lane == fl) {
-                        if (VOLS) lds_set(&s_cnt_m, cm - take_m);
-                        if (take_e) lds_set(&s_cnt_e, ce - take_e);
-                    }
-                } else if (dry && n_live == 0) {
-                    // no path, nothing to pop: this wave is done (both stacks are empty, and whoever pushes later stays)
+                const uint32_t ce = lds_get(&s_cnt_e), running = lds_get(&s_running);
+                if (n_free && ce) {
+                    // pop: idle lane number r takes the r-th record from the top
+                    const uint32_t r = lanes_below(m_free), take = ce < n_free ? ce : n_free;
+                    if (pending && r < take) pop_record(ce - 1u - r);
+                    BT_LDS_FENCE();                                           // the records are read before the count moves
+                    if ((int)lane == fl) lds_set(&s_cnt_e, ce - take);
+                } else if (n_live == 0) {
+                    // no path, nothing to pop: this wave is done (the stack is empty, and whoever pushes later stays)
                     if ((int)lane == fl) lds_set(&s_running, running - 1u);
                     leave = true;
-                } else if (dry && n_live <= (uint32_t)P.pool_push_max && running > 1u && ce + n_live <= (uint32_t)P.pool_e_cap) {
-                    // end-game: hand the last few paths to the waves that stay, and leave
+                } else if (n_live <= (uint32_t)P.pool_push_max && running > 1u && ce + n_live <= (uint32_t)P.pool_e_cap) {
+                    // hand the last few paths to the waves that stay, and leave
                     const uint32_t r = lanes_below(act & ~m_free);
-                    if (!pending) store_path(pool_e + (ce + r) * ENTRY_DW, HELD && held, held_t, held_info);
+                    if (!pending) push_record(ce + r);
                     if ((int)lane == fl) {
                         lds_set(&s_cnt_e, ce + n_live);
                         lds_set(&s_running, running - 1u);
@@ -497,17 +480,11 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 }
                 pool_unlock();
             }
-            if (leave) break;                                                 // wave-uniform
-            if (march_role && !dry) {
-                // a march-role wave more than half of whose lanes found the stack empty goes back to camera samples
-                const uint32_t still_idle = popc64(__ballot(pending));
-                if (still_idle > 32u) march_role = false;
-            }
-            if (pending && (dry || march_role)) { march_l = march_role; continue; }   // idle lane
+            if (leave) return 1;                                              // wave-uniform
+            if (pending) return 0;                                            // idle lane
         }
-        march_l = march_role;
 
-        BT_LS(1, __ballot(!pending && !(HELD && held)));
+        BT_LS(1, __ballot(!pending && !(VOTE && held)));
         if (!pending) {
             // ---- TRACE: try_hit (mod.rs:389-402) / try_hit_volume (mod.rs:404-427) ----
             const bool marching = VOLS && last_object >= 0;
@@ -526,12 +503,11 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     segments += 1;
                 }
                 const int r = lens_advance<RECTS>(P, ro, rd, lens, h, BT_LENS_BATCH, lens_steps);
-                if (r == 2) continue;                     // still on its way: no event for this lane yet
+                if (r == 2) return 0;                     // still on its way: no event for this lane yet
                 bent = false;
                 captured = r < 0;
                 travelled = lens.travelled;
-            } else if (HELD && held) {                // the hit found earlier: by this lane one iteration ago (phase voting), or
-                                                      // by the lane that pushed the path into the march stack
+            } else if (VOTE && held) {                // the hit found one iteration ago (phase voting; it travels in the path's record)
                 h.t = held_t;
                 h.prim = held_info & 0x1fffffff;
                 h.inside = (held_info >> 29) & 1;
@@ -592,7 +568,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     // sample_surface (mod.rs:454-486): emitted, then Material::shade
                     mat_index = pl.material;
                     const BtMaterial &M = S.materials[mat_index];
-                    if (!(HELD && held)) L = L + beta * mk(M.emitted);
+                    if (!(VOTE && held)) L = L + beta * mk(M.emitted);
                     if (M.kind == BT_MAT_DIFFUSE) ev = EV_DIFFUSE;
                     else if (M.kind == BT_MAT_METALLIC) ev = EV_METALLIC;
                     else if (M.kind == BT_MAT_GLASS) ev = EV_GLASS;
@@ -607,30 +583,12 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 }
             }
             if (ended) finish_sample();
-            if (HELD && ev != EV_GEN) {               // in case this lane's event loses the vote below, or its path changes lanes
+            if (VOTE && P.phase_vote && ev != EV_GEN) {       // in case this lane's event loses the vote below
                 held_t = h.t;
                 held_info = h.prim | ((int)h.inside << 29) | ((int)h.p_neg << 30);
             }
-            // a path that enters a volume (front face, not marching yet) goes to the march stack when this wave is in the
-            // surface role: the lane is free for its next camera sample
-            if (VOLS && POOL) want_push = ev == EV_VOLUME && !marching && !held && !march_role && !dry && P.pool_m_cap > 0;
         }
         pending = false;
-        if (VOLS && POOL && P.pool_m_cap) {
-            const unsigned long long m_push = __ballot(want_push);
-            if (m_push) {                                                     // wave-uniform
-                pool_lock();
-                const uint32_t cm = lds_get(&s_cnt_m), r = lanes_below(m_push), n_push = popc64(m_push);
-                const bool ok = want_push && cm + r < (uint32_t)P.pool_m_cap;
-                if (ok) store_path(pool_m + (cm + r) * ENTRY_DW, true, held_t, held_info);
-                const uint32_t cm_new = cm + n_push < (uint32_t)P.pool_m_cap ? cm + n_push : (uint32_t)P.pool_m_cap;
-                if ((int)lane == __ffsll((long long)m_push) - 1) lds_set(&s_cnt_m, cm_new);
-                pool_unlock();
-                if (ok) ev = EV_GEN;                                          // (a full stack: the path marches where it is)
-            }
-        }
-        if (HELD && !(VOTE && P.phase_vote)) held = false;                    // the hit a record brought along has been used (the
-                                                                              // vote, where it runs, settles `held` itself)
 
         if (VOTE && P.phase_vote) {
             // ---- which events run this iteration?  The kind more lanes want (camera | scatter / volume step); nobody waits
@@ -651,43 +609,39 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 waited += 1;
                 pending = want_gen;                   // no ray yet | the hit stays in held_t / held_info
                 held = !want_gen;
-                continue;
+                return 0;
             }
             waited = 0;
             held = false;
         }
 
         // ---- a lane whose path has ended (or that has none yet) moves on to its next sample ----
-        {
+        if (ENDGAME) {
+            if (ev == EV_GEN) {                                           // the queue is dry: idle until a record turns up or the wave leaves
+                pending = true;
+                return 0;
+            }
+        } else {
             const unsigned long long need = __ballot(ev == EV_GEN);
-            if (need && !dry && !march_role) {                            // one LDS atomic for the whole wave (both flags are wave-uniform)
+            if (need) {                                                   // one LDS atomic for the whole wave
                 const int leader = __ffsll((long long)need) - 1;
                 const uint32_t n_need = popc64(need);
-                uint32_t base = 0, cm_peek = 0;
-                if ((int)lane == leader) {
-                    if (VOLS && POOL) cm_peek = lds_get(&s_cnt_m);
-                    base = atomicAdd(&s_next_item, n_need);
-                }
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&s_next_item, n_need);
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
                 n_handouts = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_handouts) + 1u;
                 if (n_handouts > P.max_handouts) {                        // watchdog: this wave has been dealt more often than the block has items
                     if ((int)lane == leader && P.counters) atomicMax(&P.counters[BT_WATCHDOG_SLOT], (1ull << 32) | blockIdx.x);
                     base = n_items;
                 }
-                if (POOL && base + n_need > n_items) dry_l = true;        // the queue is exhausted (with this hand-out or before):
-                                                                          // the whole wave knows from the next iteration on
-                if (VOLS && POOL) {
-                    // enough paths wait in the march stack for a wave of their own: this one takes the role.  The items of this
-                    // hand-out are still rendered here; from the next iteration on its idle lanes pop marching paths instead
-                    cm_peek = (uint32_t)__builtin_amdgcn_readlane((int)cm_peek, leader);
-                    if (cm_peek >= (uint32_t)P.pool_m_enter && P.pool_m_cap > 0) march_l = true;
-                }
+                if (POOL && base + n_need > n_items) dry_l = true;        // the queue came back short: the wave moves on to the end-game
+                                                                          // loop at the top of its next iteration
                 if (ev == EV_GEN) {
                     const uint32_t i = base + lanes_below(need);
                     if (i >= n_items) {                                   // the block's samples are all taken
-                        if (!POOL) break;
-                        pending = true;                                   // idle: looks into the pool at the top of the loop
-                        continue;
+                        if (!POOL) return 1;                              // (lens renders: the lane is done)
+                        pending = true;
+                        return 0;
                     }
                     park_i = i;                                           // (+ the workgroup's base, see finish_sample)
                     const PixelRef r = pixel_of(P, G, B_own, i & (pxb - 1u));
@@ -695,13 +649,10 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     py = r.py;
                     if (!r.in_frame) {
                         pending = true;                                   // pixel outside the frame (edge tile): skip it
-                        continue;
+                        return 0;
                     }
                     pixel_index = py * P.width + px;
                 }
-            } else if (need && ev == EV_GEN) {
-                pending = true;                                           // dry, or a march-role wave: this lane looks into the pool at
-                continue;                                                 // the top of the loop
             }
         }
         BT_PROF(1);                                       // TRACE + hit classification
@@ -914,7 +865,14 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             pending = true;
         }
         BT_PROF(5);                                       // normalize, pdf weight (light_pdf), bookkeeping
+        return 0;
+    };
+
+    for (;;) {
+        const bool dry = POOL && __ballot(dry_l) != 0ull;     // (all lanes of the wave that are still in the loop meet here)
+        if (iteration(dry)) break;
     }
+
     // ---- the end of a workgroup --------------------------------------------------------------------------------------
     // Block queue: the last wave of the workgroup to get here performs `*r += pixel.r` (buffer.rs:159-164) for every parked
     // sample of the block's pixels, in sample order (sum_block).  The parked values were written by waves of this

@@ -197,13 +197,11 @@ struct BtLaunch {
     // the additions a lane that owned the pixel would perform, in the same order, hence the same bits.
     int32_t slices;
     float *scratch;
-    // The path pool (bt_kernels.hip "the path pool"): records of 20 dwords (28 in the AOV builds) in dynamic LDS at
-    // pool_lds_offset (16-byte aligned, behind the scene tables and the volume boxes): pool_e_cap records of the end-game
-    // stack, then pool_m_cap records of the march stack.  pool_push_max: a wave whose live paths are down to this many at the
-    // end of a block hands them over and leaves (0: never); pool_m_enter: records in the march stack that make a wave take
-    // the march role.  All zero: no path ever changes lanes (lens renders).
+    // End-game compaction (bt_kernels.hip "the path pool"): pool_e_cap records of 20 dwords (28 in the AOV builds) in dynamic
+    // LDS at pool_lds_offset (16-byte aligned, behind the scene tables and the volume boxes).  pool_push_max: a wave whose live
+    // paths are down to this many when its block's queue has run dry hands them to the waves that stay, and leaves (0: never).
     uint32_t pool_lds_offset;
-    int32_t pool_e_cap, pool_m_cap, pool_push_max, pool_m_enter;
+    int32_t pool_e_cap, pool_push_max;
     // Watchdog bounds (bt_kernels.hip): hand-outs of the work queue no wave can need (one per work item of the block, + a
     // margin) and end-game iterations no wave can need (the longest possible path with every event waiting out the phase vote,
     // x 4).  A wave that gets there has hit a scheduling bug: it reports through counters[BT_WATCHDOG_SLOT] and winds down,

@@ -234,14 +234,14 @@ def test_tuning_is_per_handle_and_validated(bendy, monkeypatch):
     process global; out-of-set values are rejected; NULL restores the defaults."""
     a = bendy.Scene.load(scene_path("scene"))
     b = bendy.Scene.load(scene_path("scene"))
-    default = dict(slices=0, phase_vote=-1, end_game=-1, march_pool=-1, march_enter=-1, scratch_cap_bytes=0)
+    default = dict(slices=0, phase_vote=-1, end_game=-1, scratch_cap_bytes=0)
     assert a.tuning() == default
-    a.set_tuning(slices=8, march_pool=64, scratch_cap_bytes=1 << 20)
-    assert a.tuning() == {**default, "slices": 8, "march_pool": 64, "scratch_cap_bytes": 1 << 20}
+    a.set_tuning(slices=8, end_game=24, scratch_cap_bytes=1 << 20)
+    assert a.tuning() == {**default, "slices": 8, "end_game": 24, "scratch_cap_bytes": 1 << 20}
     assert b.tuning() == default                     # another handle is untouched
     a.set_tuning(phase_vote=0)                       # fields not named keep their value
     assert a.tuning()["slices"] == 8 and a.tuning()["phase_vote"] == 0
-    for bad in (dict(slices=3), dict(slices=64), dict(end_game=65), dict(march_pool=-2), dict(phase_vote=65), dict(march_enter=2000)):
+    for bad in (dict(slices=3), dict(slices=64), dict(end_game=65), dict(end_game=-2), dict(phase_vote=65)):
         with pytest.raises(bendy.BendyError) as e:
             a.set_tuning(**bad)
         assert e.value.code == -1
@@ -254,7 +254,7 @@ def test_tuning_is_per_handle_and_validated(bendy, monkeypatch):
     assert c.tuning() == default
     assert c.tuning_from_env() == {"slices": 16, "end_game": 0} and c.tuning()["slices"] == 16
     with pytest.raises(TypeError):
-        c.set_tuning(tiles_per_wg=2)                 # knobs of rounds 1 and 2 that lost every measurement are gone
+        c.set_tuning(tiles_per_wg=2)                 # knobs that lost every measurement are gone (so is round 3's march_pool)
     src = open(os.path.join(ROOT, "bendy_tracer_amd", "csrc", "bt_api.cpp")).read()
     assert "getenv" not in src
 

@@ -1,7 +1,6 @@
-"""Developer tool: launches of T = 1 ... 64 rays per pixel per call on a frame (BT_FRAME, default 1920x1080) under both work
-queues and several pixel-block sizes -- the data behind bt_api.cpp's choice of queue and block size (the reference's
-interactive pattern, main.rs:245-254, is T = 1 sample x Subpixel(2) = 4).  Prints ms per pipelined call (wall) and the
-kernels' HIP-event time; modes: q1 = block queue (auto S), q2 = flow queue (auto S), q2:sN = flow queue with 256/N-pixel blocks."""
+"""Developer tool: launches of T = 1 ... 64 rays per pixel per call on a frame (BT_FRAME, default 1920x1080) under several
+pixel-block sizes -- the data behind bt_api.cpp's choice of block size (the reference's interactive pattern,
+main.rs:245-254, is T = 1 sample x Subpixel(2) = 4).  Prints ms per pipelined call (wall) and the kernel's HIP-event time."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
@@ -11,7 +10,7 @@ names = os.environ.get('BT_ONLY', 'scene,cornell2,volume').split(',')
 shapes = [(1, 1), (2, 1), (1, 2), (8, 1), (16, 1), (32, 1), (64, 1)]
 if os.environ.get('BT_T'):
     shapes = [(int(t), 1) if t != '4' else (1, 2) for t in os.environ['BT_T'].split(',')]
-modes = os.environ.get('BT_MODES', 'auto,q1,q2,q2:s1,q2:s2,q2:s4,q2:s8,q2:s16').split(',')
+modes = os.environ.get('BT_MODES', 'auto,s1,s2,s4,s8,e0').split(',')     # sN = pixel blocks of 256/N pixels; e0 = end-game compaction off
 for name in names:
     sc = b.Scene.load(f'scenes/{name}.json.gz'); cam = sc.find_by_tag('camera'); sc.set_camera_aspect(cam, w / h)
     tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
@@ -19,9 +18,10 @@ for name in names:
         row = []
         for mode in modes:
             sc.set_tuning()
-            if mode != 'auto':
-                q, _, s_ = mode.partition(':')
-                sc.set_tuning(queue=int(q[1:]), slices=int(s_[1:]) if s_ else 0)
+            if mode[0] == 's':
+                sc.set_tuning(slices=int(mode[1:]))
+            elif mode == 'e0':
+                sc.set_tuning(end_game=0)
             buf = b.Buffer.new(w, h)
             rc = b.RenderConfig.with_samples_subsample(samples, b.Subsample(sub))
             try:
@@ -37,7 +37,7 @@ for name in names:
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t) / n
                 st = sc.last_stats()
-                row.append(f'{mode}:{dt*1e3:.3f}/k{min(ks[1:]):.3f}(q{st.queue} S{st.slices})')
+                row.append(f'{mode}:{dt*1e3:.3f}/k{min(ks[1:]):.3f}(S{st.slices})')
             except Exception as e:
                 row.append(f'{mode}:err {str(e)[:40]}')
         print(f'{name:9s} {w}x{h} T={samples*sub*sub:3d} ms per call  ' + '  '.join(row), flush=True)
