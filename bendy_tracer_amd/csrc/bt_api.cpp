@@ -32,9 +32,6 @@ thread_local std::string g_error;
 thread_local int g_error_code = 0;
 constexpr uint64_t kDefaultScratchCap = 2ull << 30;   // parked sample values per launch; deeper renders are split
 constexpr uint32_t kScratchShrinkAfter = 8;           // renders in a row that need < 1/4 of the scratch before it shrinks
-// End-game compaction (bt_kernels.hip "the path pool"): default measured in round 3 (profiles/r04c, r04e)
-constexpr int32_t kEndGamePushMax = 48;               // a wave down to this many live paths at the end of a block hands them over
-constexpr size_t kLdsPerWorkgroup7 = (160 * 1024) / 7 - 128;   // dynamic LDS a workgroup may use with seven workgroups per CU
 int set_error(int code, const std::string &msg) {
     g_error = msg;
     g_error_code = code;
@@ -464,26 +461,6 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         const uint64_t pxb = 256u / (uint32_t)P.slices;
         if (pxb * chunk * nn > items_max) chunk = (uint32_t)std::max<uint64_t>(1, items_max / (pxb * nn));
     }
-    {
-        // End-game compaction (scenes with rects / cuboids, without the lens: the builds that carry its code): a stack of
-        // 3 waves x pool_push_max path records, shrunk so that seven workgroups per CU still fit their LDS
-        const size_t entry = (output == 0 ? 20 : 28) * 4;
-        P.pool_lds_offset = (uint32_t)((lds_bytes + 15) & ~(size_t)15);
-        int32_t push_max = P.lens_on || !P.any_rects ? 0 : (tune.end_game >= 0 ? tune.end_game : kEndGamePushMax);
-        if (tune.end_game < 0 && P.pool_lds_offset + 3 * (size_t)push_max * entry > kLdsPerWorkgroup7)
-            push_max = P.pool_lds_offset < kLdsPerWorkgroup7 ? (int32_t)((kLdsPerWorkgroup7 - P.pool_lds_offset) / (3 * entry)) : 0;
-        P.pool_push_max = push_max;
-        P.pool_e_cap = 3 * push_max;
-        if (P.pool_e_cap > 0) lds_bytes = P.pool_lds_offset + (size_t)P.pool_e_cap * entry;
-    }
-    {
-        // watchdog bounds (BtLaunch::max_handouts / max_dry_iters)
-        const uint64_t longest = ((uint64_t)P.max_bounces + 3) * ((uint64_t)P.max_volume_bounces + 4) *
-                                 (P.lens_on ? 2 + (uint64_t)P.lens_max_steps / 8 : 1);
-        const uint64_t items = (256u / (uint32_t)P.slices) * (uint64_t)chunk * nn;
-        P.max_handouts = (uint32_t)std::min<uint64_t>(items + 1024, 0xfffffff0u);
-        P.max_dry_iters = (uint32_t)std::min<uint64_t>(4 * (longest * 6 + 1024), 0xfffffff0u);
-    }
     const uint64_t parked_bytes = px_launch * T_all * 3 * sizeof(float);
 
 #ifdef BT_LDS_PAD                                   // developer build: unused LDS per workgroup, to time lower occupancies
@@ -524,7 +501,6 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     s->last.segments = 0;
     s->last.kernel_ms = 0.0f;
     s->last.slices = (uint32_t)P.slices;
-    s->last.pool_records = (uint32_t)P.pool_e_cap;
     s->last.launches = launches;
     s->last.scratch_bytes = s->scratch_bytes;
     s->last.parked_bytes = parked_bytes;
@@ -562,7 +538,6 @@ void bt_tuning_default(bt_tuning *t) {
     if (!t) return;
     std::memset(t, 0, sizeof *t);
     t->phase_vote = -1;
-    t->end_game = -1;
 }
 
 int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
@@ -574,8 +549,8 @@ int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
     const uint32_t S = t->slices;
     if (!(S == 0 || S == 1 || S == 2 || S == 4 || S == 8 || S == 16 || S == 32))
         return set_error(BT_ERR_INVALID_ARG, "bt_tuning.slices must be 0 (auto), 1, 2, 4, 8, 16 or 32");
-    if (t->phase_vote < -1 || t->phase_vote > 64 || t->end_game < -1 || t->end_game > 64)
-        return set_error(BT_ERR_INVALID_ARG, "bt_tuning: phase_vote and end_game must be -1 .. 64");
+    if (t->phase_vote < -1 || t->phase_vote > 64)
+        return set_error(BT_ERR_INVALID_ARG, "bt_tuning.phase_vote must be -1 .. 64");
     scene->tuning = *t;
     return 0;
 }
@@ -843,13 +818,6 @@ int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {
 #endif
         float ms = 0.0f;
         BT_HIP(hipEventElapsedTime(&ms, scene->ev_start, scene->ev_stop));
-        if (c[BT_WATCHDOG_SLOT] != 0) {
-            scene->stats_pending = false;
-            char msg[160];
-            std::snprintf(msg, sizeof msg, "render loop watchdog fired (%s, workgroup %llu): the frame of the last render is incomplete",
-                          (c[BT_WATCHDOG_SLOT] >> 32) == 1 ? "work-queue hand-outs" : "end-game iterations", c[BT_WATCHDOG_SLOT] & 0xffffffffull);
-            return set_error(BT_ERR_DEVICE, msg);
-        }
         scene->last.segments = c[0];
         scene->last.lens_steps = c[1];
         scene->last.kernel_ms = ms;

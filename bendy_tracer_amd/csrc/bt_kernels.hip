@@ -13,10 +13,6 @@
 //     their samples in this launch.  The block's (pixel, sample) pairs are a work queue in LDS: a lane whose path has
 //     ended takes the next pair, every sample's value is parked in HBM and the last wave of the workgroup adds the
 //     parked values to the frame in sample order -- the reference's per-pixel summation order, no atomics on the frame;
-//   * paths can change lanes through a small pool in LDS (72-byte records under a workgroup spin lock): at the end of a
-//     block the waves that are down to a few live paths hand them to the waves that still have many and leave (end-game
-//     compaction; a second copy of the loop body holds all of its code) -- scheduling only, every path performs the same
-//     operations in the same order;
 //   * in the sphere-only builds a wave votes every iteration whether it runs the camera event or the scatter / volume
 //     events; the lanes of the other kind keep their state for the next iteration (phase voting);
 //   * every loop iteration is TRACE (one path segment, all lanes) followed by exactly ONE random event per lane --
@@ -33,6 +29,10 @@
 // Round 3 removed what had lost every measurement of rounds 1 and 2 (the logs stay under profiles/): the lane-owns-pixel
 // mapping, the streaming queue with its ring of parked units, the regrouping kernel (bt_kernels_sorted.hip) and the A/B
 // knobs BT_VOTE3, BT_VOTE_SOFT_K, BT_XCD_ROTATE, BT_PK_PAIRS, BT_WG_THREADS, BT_VOTE_RECTS, BT_NUM_SGPR, BT_WAVES_EXACT.
+// Round 3's own experiments are gone again too, each bit-exact and each measured slower or no faster: persistent workgroups
+// that claim pixel blocks with the sums in a second kernel (profiles/r04b), a pool of path records in LDS through which paths
+// change lanes -- a "march stack" for paths that enter a volume (profiles/r04d) and end-of-block compaction (profiles/r04c,
+// r04e, r04f).
 #include "bt_device.hpp"
 
 // Developer build (-DBT_PROFILE): s_memtime stamps around the sections of the render loop, summed per wave into
@@ -64,18 +64,6 @@ enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 
 BT_DEV uint32_t lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-// a word of the workgroup's LDS state, read / written as such (ds_read_b32 / ds_write_b32; a volatile generic pointer would
-// make it a flat access)
-BT_DEV uint32_t lds_get(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-BT_DEV void lds_set(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// the lanes that execute THIS instruction: EXEC read in place (a `__ballot(true)` is an expression the optimizer may
-// evaluate earlier, where lanes that have since left for the loop head still count)
-BT_DEV unsigned long long exec_here() {
-    unsigned long long m;
-    asm volatile("s_mov_b64 %0, exec" : "=s"(m));
-    return m;
-}
-
 // ---- where a pixel block lies in the frame ---------------------------------------------------------------------------
 // BtLaunch::slices = NS in {1,2,4,8,16,32}: a 16x16 tile is cut into NS blocks of pxb = 256/NS pixels -- whole 8x8 quadrants
 // down to 64 pixels, then 8x4, 4x4, 4x2 pixels, numbered row-major inside the tile.  Block b of the launch is block
@@ -211,12 +199,8 @@ BT_DEV void sum_block(const BtLaunch &P, const BlockGeom &g, uint32_t b, uint32_
 #define BT_WAVES_PER_SIMD_LENS 6       // lens builds: 80 VGPRs + ~100 B of scratch per lane still beat 4 waves without
 #endif                                 // scratch (665 -> 719 Msamples/s, profiles/r01g/ab_lens_waves.log)
 // LENS switches the (non-reference, default-off) gravitational-lens extension of bt_device.hpp in.
-#define BT_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local")   // orders LDS accesses only (lgkmcnt)
 #ifndef BT_SKIP_DIR
 #define BT_SKIP_DIR 1          // a wave of pass-through march steps skips the direction sampling
-#endif
-#ifndef BT_POOL
-#define BT_POOL 1              // 0: no end-game compaction code at all (A/B knob)
 #endif
 #ifndef BT_LENS_BATCH
 #define BT_LENS_BATCH 8            // RK4 steps a lane marches per loop iteration before it yields
@@ -229,16 +213,10 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     __shared__ uint32_t s_waves_done;      // block queue: waves of this workgroup that have parked all their samples
     __shared__ uint32_t s_next_item;       // the workgroup's work queue (next unclaimed (pixel, sample) pair)
     __shared__ uint32_t s_segments;        // path segments traced by this workgroup
-    __shared__ uint32_t s_pool_lock;       // path pool: spin lock of this workgroup's waves (0 = free)
-    __shared__ uint32_t s_running;         // path pool: waves that have not left the render loop yet
-    __shared__ uint32_t s_cnt_e;           // path pool: records in the end-game stack
     if (threadIdx.x == 0) {
         s_waves_done = 0;
         s_next_item = 0;
         s_segments = 0;
-        s_pool_lock = 0;
-        s_running = blockDim.x >> 6;
-        s_cnt_e = 0;
     }
 
     // ---- stage the per-lane lookup tables in LDS ----
@@ -324,10 +302,6 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     bool pending = true;               // the lane has no ray yet: its next event is the camera ray
     // phase voting (BtLaunch::phase_vote): a lane whose scatter event lost the vote keeps its hit for the next iteration
     constexpr bool VOTE = !RECTS && !LENS;    // pays where the events, not TRACE, are most of an iteration
-    // End-game compaction (below) is compiled into the rect builds only: there it pays (C2 -11 %, Cornell -1 %); in the sphere
-    // builds its code costs the hot loop more registers than its idle lanes are worth (C3 +4 %, C4 +9 % net, as one loop or as
-    // two: profiles/r04c, r04e), and the lens extension keeps a bent segment's state per lane.
-    constexpr bool POOL = !LENS && RECTS && BT_POOL;
     bool held = false;
     float held_t = 0.0f;
     int held_info = 0, waited = 0;     // held_info = prim | inside << 29 | p_neg << 30
@@ -355,82 +329,12 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         ((Parked *)P.scratch + (size_t)blockIdx.x * n_items)[park_i] = Parked{value.x, value.y, value.z};
     };
 
-    // ---- end-game compaction: the path pool ---------------------------------------------------------------------------------
-    // When a block's queue has run dry a workgroup used to drain: every wave kept issuing for its last few long paths (4.6 %
-    // of all lane slots on C3, 10 % on C4, 28 % on C2, profiles/r02d/lanestat_block_queue.log).  Now a wave that is down to
-    // <= pool_push_max live paths pushes them into a stack of records in LDS and leaves; the idle lanes of the waves that stay
-    // pop them.  A path between two loop iterations is 20 dwords (ray, throughput, radiance, its work item, counters, a hit it
-    // may be holding for the phase vote; 25 with the AOV registers); the stack lives in dynamic LDS behind the scene tables,
-    // under a spin lock (four waves contend; the holder never waits for anything else).  The last running wave never pushes,
-    // and a wave leaves empty-handed only when the stack is empty -- both checked under the lock, so no record is stranded.
-    // Scheduling only: a record is restored bit for bit, Philox is keyed by (pixel, sample, event), the parked value goes to
-    // the item's own slot -- every path performs the same operations in the same order on whichever lane it sits.
-    // `dry` must be wave-uniform -- a hand-out whose leader lane sat in another branch would deal the same items again, for
-    // ever -- but it is learnt by whichever lanes stand at the hand-out.  So every lane carries a copy (dry_l), and the top of
-    // the loop, where all lanes of the wave meet, turns the copies into one ballot-derived value per iteration.
-    // (A second copy of the loop body for the end-game, so that the main loop carries none of this code, was slower on every
-    // scene: profiles/r04e.)
-    constexpr uint32_t ENTRY_DW = OUTPUT == 0 ? 20u : 28u;      // (25 used in the AOV builds)
-    uint32_t *const pool_e = (uint32_t *)(smem + P.pool_lds_offset);
-    bool dry_l = false;                // this lane has seen the queue come back short (any lane of the wave: the wave is "dry")
-    // Watchdog: a scheduling bug must end in an error code, never in a hung GPU.  Two wave-uniform counters at decisions the
-    // loops take anyway: hand-outs of the work queue (more than the block has items: the queue is declared dry) and iterations
-    // of the end-game (more than the longest path can need: the wave leaves).  Both report through counters[BT_WATCHDOG_SLOT].
-    uint32_t n_handouts = 0, n_dry_iters = 0;
-    auto pool_lock = [&]() {           // (the holder never waits for anything: a critical section is a few dozen LDS accesses)
-        const int fl = __ffsll((long long)exec_here()) - 1;
-        if ((int)lane == fl)
-            while (atomicCAS(&s_pool_lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
-        BT_LDS_FENCE();
-    };
-    auto pool_unlock = [&]() {
-        BT_LDS_FENCE();
-        const int fl = __ffsll((long long)exec_here()) - 1;
-        if ((int)lane == fl) __hip_atomic_store(&s_pool_lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    // A record is written and read one dword at a time, straight out of / into the registers that hold the path (volatile
-    // accesses with immediate offsets: ds_write_b32 / ds_read_b32 for the stack in LDS).  Packing it into 128-bit accesses
-    // needs twenty more registers at a point where everything else is live; a record moves once per path and end of block.
-    typedef volatile __attribute__((address_space(3))) uint32_t LdsWord;
-    typedef volatile __attribute__((address_space(3))) float LdsFloat;
-    auto store_path = [&](auto *f, auto *w, bool with_hit, float hit_t, int hit_info) {
-        f[0] = ro.x; f[1] = ro.y; f[2] = ro.z; f[3] = rd.x; f[4] = rd.y; f[5] = rd.z;
-        f[6] = beta.x; f[7] = beta.y; f[8] = beta.z; f[9] = L.x; f[10] = L.y; f[11] = L.z;
-        w[12] = park_i; w[13] = pixel_index; w[14] = event; w[15] = (uint32_t)bounce;
-        w[16] = (uint32_t)vbounce; w[17] = (uint32_t)last_object; f[18] = hit_t;
-        w[19] = ((uint32_t)hit_info & 0x7fffffffu) | (with_hit ? 0x80000000u : 0u);
-        if (OUTPUT != 0) {
-            f[20] = first.x; f[21] = first.y; f[22] = first.z; f[23] = first_depth; w[24] = have_first ? 1u : 0u;
-        }
-    };
-    auto load_path = [&](auto *f, auto *w) {
-        ro.x = f[0]; ro.y = f[1]; ro.z = f[2]; rd.x = f[3]; rd.y = f[4]; rd.z = f[5];
-        beta.x = f[6]; beta.y = f[7]; beta.z = f[8]; L.x = f[9]; L.y = f[10]; L.z = f[11];
-        park_i = w[12]; pixel_index = w[13]; event = w[14]; bounce = (int)w[15];
-        vbounce = (int)w[16]; last_object = (int)w[17];
-        held_t = f[18];
-        const uint32_t info = w[19];
-        held = VOTE && (info >> 31) != 0u;
-        held_info = (int)(info & 0x7fffffffu);
-        if (OUTPUT != 0) {
-            first.x = f[20]; first.y = f[21]; first.z = f[22]; first_depth = f[23]; have_first = w[24] != 0u;
-        }
-    };
-    auto push_record = [&](uint32_t slot) { store_path((LdsFloat *)(pool_e + slot * ENTRY_DW), (LdsWord *)(pool_e + slot * ENTRY_DW), VOTE && held, held_t, held_info); };
-    auto pop_record = [&](uint32_t slot) {
-        load_path((LdsFloat *)(pool_e + slot * ENTRY_DW), (LdsWord *)(pool_e + slot * ENTRY_DW));
-        pending = false;
-        waited = 0;
-    };
-
     BT_PROF_DECL;
 #ifdef BT_LANESTAT
     unsigned long long ls_acc[9] = {};
     const unsigned long long ls_all = __ballot(true);
 #endif
-    // One loop iteration; ENDGAME (wave-uniform): the block's queue is dry, the pool code runs instead of the hand-out.
-    // Returns 0 to go on (what `continue` was), 1 when this lane -- in the end-game: this wave -- leaves the loop.
-    auto iteration = [&](const bool ENDGAME) __attribute__((always_inline)) -> int {
+    for (;;) {
         BT_LS(0, 1ull);
         BT_LS(8, ls_all & ~__ballot(true));
         BT_PROF(0);                                       // loop overhead / previous iteration's tail
@@ -443,46 +347,6 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         V3 prim_c = mk(0, 0, 0);
         float prim_radius = 0.0f;
         int hit_prim = 0;
-
-        if (ENDGAME) {
-            // ---- idle lanes look for a path in the pool; a wave with few paths left hands them over; an empty wave leaves ----
-            const unsigned long long act = exec_here(), m_free = __ballot(pending);
-            const uint32_t n_free = popc64(m_free), n_live = popc64(act) - n_free;
-            const int fl = __ffsll((long long)act) - 1;
-            bool leave = false;
-            n_dry_iters = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_dry_iters) + 1u;     // (wave-uniform: lives in an SGPR)
-            // (the count is peeked at without the lock: a stale value costs one more look in the next iteration)
-            if (n_dry_iters > P.max_dry_iters) {                              // watchdog
-                if ((int)lane == fl && P.counters) atomicMax(&P.counters[BT_WATCHDOG_SLOT], (2ull << 32) | blockIdx.x);
-                leave = true;
-            } else if ((n_free && lds_get(&s_cnt_e)) || n_live <= (uint32_t)P.pool_push_max) {
-                pool_lock();
-                const uint32_t ce = lds_get(&s_cnt_e), running = lds_get(&s_running);
-                if (n_free && ce) {
-                    // pop: idle lane number r takes the r-th record from the top
-                    const uint32_t r = lanes_below(m_free), take = ce < n_free ? ce : n_free;
-                    if (pending && r < take) pop_record(ce - 1u - r);
-                    BT_LDS_FENCE();                                           // the records are read before the count moves
-                    if ((int)lane == fl) lds_set(&s_cnt_e, ce - take);
-                } else if (n_live == 0) {
-                    // no path, nothing to pop: this wave is done (the stack is empty, and whoever pushes later stays)
-                    if ((int)lane == fl) lds_set(&s_running, running - 1u);
-                    leave = true;
-                } else if (n_live <= (uint32_t)P.pool_push_max && running > 1u && ce + n_live <= (uint32_t)P.pool_e_cap) {
-                    // hand the last few paths to the waves that stay, and leave
-                    const uint32_t r = lanes_below(act & ~m_free);
-                    if (!pending) push_record(ce + r);
-                    if ((int)lane == fl) {
-                        lds_set(&s_cnt_e, ce + n_live);
-                        lds_set(&s_running, running - 1u);
-                    }
-                    leave = true;
-                }
-                pool_unlock();
-            }
-            if (leave) return 1;                                              // wave-uniform
-            if (pending) return 0;                                            // idle lane
-        }
 
         BT_LS(1, __ballot(!pending && !(VOTE && held)));
         if (!pending) {
@@ -503,7 +367,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     segments += 1;
                 }
                 const int r = lens_advance<RECTS>(P, ro, rd, lens, h, BT_LENS_BATCH, lens_steps);
-                if (r == 2) return 0;                     // still on its way: no event for this lane yet
+                if (r == 2) continue;                     // still on its way: no event for this lane yet
                 bent = false;
                 captured = r < 0;
                 travelled = lens.travelled;
@@ -609,47 +473,30 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 waited += 1;
                 pending = want_gen;                   // no ray yet | the hit stays in held_t / held_info
                 held = !want_gen;
-                return 0;
+                continue;
             }
             waited = 0;
             held = false;
         }
 
         // ---- a lane whose path has ended (or that has none yet) moves on to its next sample ----
-        if (ENDGAME) {
-            if (ev == EV_GEN) {                                           // the queue is dry: idle until a record turns up or the wave leaves
-                pending = true;
-                return 0;
-            }
-        } else {
+        {
             const unsigned long long need = __ballot(ev == EV_GEN);
             if (need) {                                                   // one LDS atomic for the whole wave
                 const int leader = __ffsll((long long)need) - 1;
-                const uint32_t n_need = popc64(need);
                 uint32_t base = 0;
-                if ((int)lane == leader) base = atomicAdd(&s_next_item, n_need);
+                if ((int)lane == leader) base = atomicAdd(&s_next_item, popc64(need));
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                n_handouts = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_handouts) + 1u;
-                if (n_handouts > P.max_handouts) {                        // watchdog: this wave has been dealt more often than the block has items
-                    if ((int)lane == leader && P.counters) atomicMax(&P.counters[BT_WATCHDOG_SLOT], (1ull << 32) | blockIdx.x);
-                    base = n_items;
-                }
-                if (POOL && base + n_need > n_items) dry_l = true;        // the queue came back short: the wave moves on to the end-game
-                                                                          // loop at the top of its next iteration
                 if (ev == EV_GEN) {
                     const uint32_t i = base + lanes_below(need);
-                    if (i >= n_items) {                                   // the block's samples are all taken
-                        if (!POOL) return 1;                              // (lens renders: the lane is done)
-                        pending = true;
-                        return 0;
-                    }
+                    if (i >= n_items) break;                              // the block's samples are all taken
                     park_i = i;                                           // (+ the workgroup's base, see finish_sample)
                     const PixelRef r = pixel_of(P, G, B_own, i & (pxb - 1u));
                     px = r.px;
                     py = r.py;
                     if (!r.in_frame) {
                         pending = true;                                   // pixel outside the frame (edge tile): skip it
-                        return 0;
+                        continue;
                     }
                     pixel_index = py * P.width + px;
                 }
@@ -865,12 +712,6 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             pending = true;
         }
         BT_PROF(5);                                       // normalize, pdf weight (light_pdf), bookkeeping
-        return 0;
-    };
-
-    for (;;) {
-        const bool dry = POOL && __ballot(dry_l) != 0ull;     // (all lanes of the wave that are still in the loop meet here)
-        if (iteration(dry)) break;
     }
 
     // ---- the end of a workgroup --------------------------------------------------------------------------------------

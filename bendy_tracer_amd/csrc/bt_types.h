@@ -10,7 +10,6 @@
 #define BT_N_COUNTERS 2
 #endif
 #define BT_DENSITY_LDS_MAX 8192   // density maps up to this many cells are staged in LDS (32 KB)
-#define BT_WATCHDOG_SLOT 14      // d_counters[14]: non-zero when a wave left the render loop through its watchdog (bt_kernels.hip)
 
 struct BtV3 { float x, y, z; };
 
@@ -197,16 +196,6 @@ struct BtLaunch {
     // the additions a lane that owned the pixel would perform, in the same order, hence the same bits.
     int32_t slices;
     float *scratch;
-    // End-game compaction (bt_kernels.hip "the path pool"): pool_e_cap records of 20 dwords (28 in the AOV builds) in dynamic
-    // LDS at pool_lds_offset (16-byte aligned, behind the scene tables and the volume boxes).  pool_push_max: a wave whose live
-    // paths are down to this many when its block's queue has run dry hands them to the waves that stay, and leaves (0: never).
-    uint32_t pool_lds_offset;
-    int32_t pool_e_cap, pool_push_max;
-    // Watchdog bounds (bt_kernels.hip): hand-outs of the work queue no wave can need (one per work item of the block, + a
-    // margin) and end-game iterations no wave can need (the longest possible path with every event waiting out the phase vote,
-    // x 4).  A wave that gets there has hit a scheduling bug: it reports through counters[BT_WATCHDOG_SLOT] and winds down,
-    // and the render returns BT_ERR_DEVICE instead of hanging the GPU.
-    uint32_t max_handouts, max_dry_iters;
     uint32_t tiles_x_magic;           // floor(2^32 / tiles_x) (0xffffffff for tiles_x = 1): tile / tiles_x = umulhi(tile, magic), fixed up by one step
     uint32_t table_lds_bytes;         // bytes of the scene tables at the start of dynamic LDS
     // Scenes with volumes: behind the tables one BtVolBox per primitive (48 B; filled by the kernel's prologue for the

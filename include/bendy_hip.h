@@ -86,8 +86,7 @@ typedef struct {
     uint32_t launches;         /* kernel launches the render was split into (deep renders under the scratch cap) */
     uint64_t scratch_bytes;    /* HBM the handle holds for parked sample values after this render */
     uint64_t parked_bytes;     /* bytes of sample values the render parked in HBM (12 per sample, edge tiles padded) */
-    uint32_t pool_records;     /* path records a workgroup of the last launch could hold in LDS (end-game compaction; 0 = off) */
-    uint32_t reserved;
+    uint32_t reserved[2];
 } bt_stats;
 
 /* Launch-shape knobs of a scene handle.  Every field's zero / negative value means "let the library decide" (what
@@ -96,9 +95,6 @@ typedef struct {
 typedef struct {
     uint32_t slices;           /* 0 = auto; 1, 2, 4, 8, 16, 32: pixel blocks of 256 / slices pixels */
     int32_t phase_vote;        /* -1 = auto; 0 = off; n = longest wait of the phase vote in iterations */
-    int32_t end_game;          /* -1 = auto; 0 = off; n: at the end of a pixel block a wave that is down to n live paths hands them to
-                                * the waves that stay (through a stack of path records in LDS) and leaves */
-    uint32_t reserved;
     uint64_t scratch_cap_bytes;/* 0 = the default 2 GiB: most parked sample values per launch; deeper renders are split into
                                 * several launches over consecutive sample ranges */
 } bt_tuning;

@@ -290,56 +290,6 @@ def test_shallow_launches(bendy, oracle, name, samples, n, world):
         assert np.array_equal(out.numpy(), it)
 
 
-# ---- the path pool: paths change lanes through LDS records (end-game compaction) -- scheduling only ------------------
-POOL_SETTINGS = [
-    dict(end_game=0),                    # nothing ever changes lanes
-    dict(end_game=64),                   # every wave but the last hands over whatever it has when the queue runs dry
-    dict(end_game=1),
-    dict(end_game=7),
-    dict(end_game=40),
-]
-
-
-@pytest.mark.parametrize("knobs", POOL_SETTINGS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
-@pytest.mark.parametrize("name,w,h,spp,n,output", [
-    ("cloud", 96, 64, 12, 0, 0),
-    ("volume", 70, 41, 5, 2, 0),         # ragged, Subpixel(2)
-    ("cornell2", 64, 48, 9, 0, 0),
-    ("cornell", 70, 41, 5, 2, 0),        # ragged, Subpixel(2)
-    ("cornell", 96, 54, 24, 0, 0),
-    ("cornell2", 64, 48, 8, 0, 2),       # AOV registers travel in the record (Normal)
-    ("cornell", 48, 32, 6, 0, 3),        # ... and the first depth
-    ("scene", 96, 54, 24, 0, 0),         # (sphere build: the knob is accepted and does nothing)
-])
-def test_path_pool_is_scheduling_only(bendy, oracle, name, w, h, spp, n, output, knobs):
-    """A path's record (ray, throughput, radiance, work item, counters, held hit, AOV registers) is restored bit for bit on
-    whichever lane pops it; Philox is keyed by (pixel, sample, event) and the parked value goes to the item's own slot.
-    Every setting of the pool -- off, greedy, stingy -- must give the oracle's frame and segment count."""
-    buf, stats, _ = gpu_render(bendy, name, w, h, spp, n=n, output=output, tuning=knobs)
-    it, seg = oracle_render(oracle, name, w, h, spp, n=n, output=output)
-    assert stats.segments == seg and np.array_equal(buf.numpy(), it)
-
-
-@pytest.mark.parametrize("seed", [0, 3, 5, 9, 13, 17, 18, 19, 22])
-def test_path_pool_random_scenes(bendy, oracle, seed):
-    test_random_scenes_bit_exact(bendy, oracle, seed, tuning=dict(end_game=48))
-
-
-def test_path_pool_only_where_its_code_is(bendy):
-    """End-game compaction is compiled into the rect builds; sphere-only scenes and the lens extension (a bent segment's
-    state stays on its lane) render without it, whatever bt_tuning.end_game says."""
-    sc, cam = gpu_scene(bendy, "cornell2", 64, 48)
-    buf = bendy.Buffer.new(64, 48)
-    bendy.Tracer.new().render(sc, cam, bendy.RenderConfig.with_samples(2), buf)
-    assert sc.last_stats().pool_records == 3 * 48
-    sc.set_lens(centre=(0.0, 2.0, -2.0), rs=0.15, step=0.25, radius=3.0, max_steps=200)
-    bendy.Tracer.new().render(sc, cam, bendy.RenderConfig.with_samples(2), buf)
-    assert sc.last_stats().pool_records == 0
-    sc, cam = gpu_scene(bendy, "scene", 64, 48, tuning=dict(end_game=32))
-    bendy.Tracer.new().render(sc, cam, bendy.RenderConfig.with_samples(2), buf)
-    assert sc.last_stats().pool_records == 0
-
-
 @pytest.mark.parametrize("max_wait", [0, 1, 2, 7])
 @pytest.mark.parametrize("name,w,h,spp", [("scene", 96, 54, 24), ("cloud", 64, 48, 12)])
 def test_phase_vote_is_scheduling_only(bendy, oracle, name, w, h, spp, max_wait):
@@ -579,17 +529,10 @@ def test_density_map_larger_than_the_lds_budget(bendy, oracle):
         _compare_json_scene(bendy, oracle, random_scene(seed, n_objects=6, volume_prob=1.0, density_dims=(24,)), 64, 40, 4)
 
 
-# ---- the path pool at full size ---------------------------------------------------------------------------------------
-def test_path_pool_at_full_size(bendy, oracle):
-    """BASELINE configs[1] (cornell2 512 x 512 x 16 spp) whole against the oracle with the pool off and on; the 1080p Cornell
-    box at 64 spp with the pool off == on."""
-    it, seg = oracle_render(oracle, "cornell2", 512, 512, 16, threads=_host_threads())
-    for knobs in (dict(end_game=0), dict()):
-        buf, st, _ = gpu_render(bendy, "cornell2", 512, 512, 16, tuning=knobs)
-        assert st.segments == seg and np.array_equal(buf.numpy(), it), knobs
-    a, sa, _ = gpu_render(bendy, "cornell", 1920, 1080, 64, tuning=dict(end_game=0))
-    b_, sb, _ = gpu_render(bendy, "cornell", 1920, 1080, 64)
-    assert sa.pool_records == 0 and sb.pool_records > 0 and sa.segments == sb.segments and np.array_equal(a.numpy(), b_.numpy())
+# ---- BASELINE configs[1] at full size ---------------------------------------------------------------------------------
+def test_c2_cornell2_512_16spp(bendy, oracle):
+    """BASELINE configs[1] (cornell2.json.gz 512 x 512 x 16 spp): the whole frame and the segment count against the oracle."""
+    _full_frame(bendy, oracle, "cornell2", 512, 512, 16)
 
 
 

@@ -234,14 +234,14 @@ def test_tuning_is_per_handle_and_validated(bendy, monkeypatch):
     process global; out-of-set values are rejected; NULL restores the defaults."""
     a = bendy.Scene.load(scene_path("scene"))
     b = bendy.Scene.load(scene_path("scene"))
-    default = dict(slices=0, phase_vote=-1, end_game=-1, scratch_cap_bytes=0)
+    default = dict(slices=0, phase_vote=-1, scratch_cap_bytes=0)
     assert a.tuning() == default
-    a.set_tuning(slices=8, end_game=24, scratch_cap_bytes=1 << 20)
-    assert a.tuning() == {**default, "slices": 8, "end_game": 24, "scratch_cap_bytes": 1 << 20}
+    a.set_tuning(slices=8, phase_vote=5, scratch_cap_bytes=1 << 20)
+    assert a.tuning() == {**default, "slices": 8, "phase_vote": 5, "scratch_cap_bytes": 1 << 20}
     assert b.tuning() == default                     # another handle is untouched
     a.set_tuning(phase_vote=0)                       # fields not named keep their value
     assert a.tuning()["slices"] == 8 and a.tuning()["phase_vote"] == 0
-    for bad in (dict(slices=3), dict(slices=64), dict(end_game=65), dict(end_game=-2), dict(phase_vote=65)):
+    for bad in (dict(slices=3), dict(slices=64), dict(phase_vote=-2), dict(phase_vote=65)):
         with pytest.raises(bendy.BendyError) as e:
             a.set_tuning(**bad)
         assert e.value.code == -1
@@ -249,12 +249,12 @@ def test_tuning_is_per_handle_and_validated(bendy, monkeypatch):
     assert a.tuning() == default
     # the library ignores the environment; only the helper for tools / tests translates it
     monkeypatch.setenv("BT_SLICES", "16")
-    monkeypatch.setenv("BT_END_GAME", "0")
+    monkeypatch.setenv("BT_PHASE_VOTE", "2")
     c = bendy.Scene.load(scene_path("scene"))
     assert c.tuning() == default
-    assert c.tuning_from_env() == {"slices": 16, "end_game": 0} and c.tuning()["slices"] == 16
+    assert c.tuning_from_env() == {"slices": 16, "phase_vote": 2} and c.tuning()["slices"] == 16
     with pytest.raises(TypeError):
-        c.set_tuning(tiles_per_wg=2)                 # knobs that lost every measurement are gone (so is round 3's march_pool)
+        c.set_tuning(tiles_per_wg=2)                 # knobs that lost every measurement are gone (so are round 3's queue, end_game and march_pool)
     src = open(os.path.join(ROOT, "bendy_tracer_amd", "csrc", "bt_api.cpp")).read()
     assert "getenv" not in src
 

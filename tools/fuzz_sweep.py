@@ -28,7 +28,7 @@ for seed in range(first, first + n):
     out = seed % 4
     gs = bendy.Scene.from_json(txt); cam = gs.find_by_tag("camera"); gs.set_camera_aspect(cam, w / h)
     if seed % 2 == 0:
-        gs.set_tuning(end_game=seed % 64)           # every other scene with an odd end-game threshold
+        gs.set_tuning(slices=1 << (seed % 6), phase_vote=seed % 9)     # every other scene with a pinned block size and vote wait
     buf = bendy.Buffer.new(w, h)
     bendy.Tracer.with_config(bendy.Config(output=bendy.Output(out))).render(gs, cam, bendy.RenderConfig.with_samples(spp), buf, seed=seed)
     torch.cuda.synchronize()
