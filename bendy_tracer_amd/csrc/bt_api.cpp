@@ -31,6 +31,7 @@ namespace {
 thread_local std::string g_error;
 thread_local int g_error_code = 0;
 constexpr uint64_t kDefaultScratchCap = 2ull << 30;   // parked sample values per launch; deeper renders are split
+constexpr uint32_t kCounterSlots = 64;                // work counters: one memset per 64 renders instead of one per render
 constexpr uint32_t kScratchShrinkAfter = 8;           // renders in a row that need < 1/4 of the scratch before it shrinks
 int set_error(int code, const std::string &msg) {
     g_error = msg;
@@ -80,7 +81,9 @@ struct bt_scene {
     DeviceArray<int32_t> d_lens_prims;     // lens extension: rows of d_prims near the sphere of influence
     bt_lens lens_prims_for{};              // the lens d_lens_prims was built for
     bool lens_prims_valid = false;
-    unsigned long long *d_counters = nullptr;
+    unsigned long long *d_counters = nullptr;   // kCounterSlots x 16 words: render number n counts into slot n mod kCounterSlots
+    uint32_t render_seq = 0;       // renders issued on this handle (selects the counter slot)
+    uint32_t last_slot = 0;
     float *d_scratch = nullptr;    // parked sample values of sliced renders
     size_t scratch_bytes = 0;
     uint32_t scratch_small_streak = 0;   // consecutive renders that needed less than a quarter of the scratch held
@@ -176,7 +179,10 @@ int ensure_device(bt_scene *s) {
     BT_HIP(s->d_aan_rows.upload(s->flat.aan_rows));
     BT_HIP(s->d_la_rows.upload(s->flat.la_rows));
     BT_HIP(s->d_other_rows.upload(s->flat.other_rows));
-    if (!s->d_counters) BT_HIP(hipMalloc((void **)&s->d_counters, 16 * sizeof(unsigned long long)));
+    if (!s->d_counters) {
+        BT_HIP(hipMalloc((void **)&s->d_counters, kCounterSlots * 16 * sizeof(unsigned long long)));
+        s->render_seq = 0;
+    }
     if (!s->ev_start) BT_HIP(hipEventCreate(&s->ev_start));
     if (!s->ev_stop) BT_HIP(hipEventCreate(&s->ev_stop));
     s->device = dev;
@@ -325,7 +331,7 @@ int fill_launch(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt
     P.rank = 0;
     P.world = 1;
     P.sharded = 0;
-    P.counters = s->d_counters;
+    P.counters = s->d_counters;                 // (render_common points it at this render's slot)
     P.lens_on = s->lens_on ? 1 : 0;
     P.lens_c.x = s->lens.centre[0]; P.lens_c.y = s->lens.centre[1]; P.lens_c.z = s->lens.centre[2];
     P.lens_rs = s->lens.rs;
@@ -473,7 +479,12 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     // (profiles/r01f/ab_phase_vote.log, profiles/r01g/ab_vote_both.log)
     P.phase_vote = tune.phase_vote >= 0 ? tune.phase_vote : (P.any_volumes ? 4 : 3);
     uint32_t launches = 0;
-    BT_HIP(hipMemsetAsync(s->d_counters, 0, 15 * sizeof(unsigned long long), stream));
+    // work counters: a ring of slots, zeroed all at once when the ring wraps -- the interactive loop (main.rs:245-254, one
+    // render per displayed frame) then pays one memset per 64 frames instead of one per frame in front of a 0.1 ms kernel
+    s->last_slot = s->render_seq % kCounterSlots;
+    if (s->last_slot == 0) BT_HIP(hipMemsetAsync(s->d_counters, 0, kCounterSlots * 16 * sizeof(unsigned long long), stream));
+    s->render_seq += 1;
+    P.counters = s->d_counters + (size_t)s->last_slot * 16;
     BT_HIP(hipEventRecord(s->ev_start, stream));
     {
         const uint32_t all = (uint32_t)P.samples, base = P.sample_base;
@@ -797,7 +808,7 @@ int bt_scene_last_stats(bt_scene *scene, bt_stats *out) {
     if (scene->stats_pending) {
         BT_HIP(hipEventSynchronize(scene->ev_stop));
         unsigned long long c[16] = {0, 0};
-        BT_HIP(hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
+        BT_HIP(hipMemcpy(c, scene->d_counters + (size_t)scene->last_slot * 16, sizeof c, hipMemcpyDeviceToHost));
 #ifdef BT_LANESTAT
         // developer build (-DBT_LANESTAT): what the lanes of a wave do per iteration, see bt_kernels.hip
         if (c[2]) {

@@ -127,6 +127,9 @@ int bt_allgather_shards_device(bt_comm *comm, const float *shard_device, float *
                                uint32_t height, void *stream) {
     if (!comm || !shard_device || !gathered_device || width == 0 || height == 0)
         return bt_set_error_internal(BT_ERR_INVALID_ARG, "bt_allgather_shards_device: null / zero argument");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != comm->device)        // the communicator lives on the device it was created on
+        return bt_set_error_internal(BT_ERR_INVALID_ARG, "bt_allgather_shards_device: the current device is not the communicator's (hipSetDevice first)");
     const size_t count = bt_shard_floats(width, height, comm->world);
     const int e = rccl().AllGather(shard_device, gathered_device, count, kNcclFloat, comm->comm, (hipStream_t)stream);
     if (e != kNcclSuccess) return rccl_error("ncclAllGather", e);

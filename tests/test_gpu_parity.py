@@ -300,6 +300,36 @@ def test_phase_vote_is_scheduling_only(bendy, oracle, name, w, h, spp, max_wait)
     assert stats.segments == seg and np.array_equal(buf.numpy(), it)
 
 
+def test_default_sample_base_after_a_change_of_subsample(bendy, oracle):
+    """Tracer.render's default sample_base is the next UNUSED sample index (ceil(buffer.samples / n^2)): three calls with
+    Subsample::None and then one with Subpixel(2) -- through the default -- must equal the same four calls with the sample bases
+    spelled out (0, 1, 2 and then 1 in Subpixel(2)'s numbering, not floor(3 / 4) = 0, which would replay index 0..3), and the
+    oracle given those bases."""
+    w, h = 64, 40
+    sc, cam = gpu_scene(bendy, "scene", w, h)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    one, sub = bendy.RenderConfig.with_samples(1), bendy.RenderConfig.with_samples_subsample(1, bendy.Subsample(2))
+    a, b_ = bendy.Buffer.new(w, h), bendy.Buffer.new(w, h)
+    for _ in range(3):
+        tr.render(sc, cam, one, a)
+    tr.render(sc, cam, sub, a)
+    for i in range(3):
+        tr.render(sc, cam, one, b_, sample_base=i)
+    tr.render(sc, cam, sub, b_, sample_base=1)
+    assert a.samples == b_.samples == 7 and np.array_equal(a.numpy(), b_.numpy())
+    first, _ = oracle_render(oracle, "scene", w, h, 3)
+    last, _ = oracle_render(oracle, "scene", w, h, 1, n=2, sample_base=1)
+    want = first.copy()
+    want[..., :3] = first[..., :3] + last[..., :3]          # `*r += pixel.r` call after call (buffer.rs:159-164)
+    floor_version = bendy.Buffer.new(w, h)
+    for i in range(3):
+        tr.render(sc, cam, one, floor_version, sample_base=i)
+    tr.render(sc, cam, sub, floor_version, sample_base=0)
+    assert not np.array_equal(a.numpy(), floor_version.numpy())
+    # (the two oracle frames are summed in float here, the kernel adds sample by sample: equal to a few ulp, not bit for bit)
+    assert np.abs(a.numpy()[..., :3] - want[..., :3]).max() <= 1e-5 * max(1.0, float(np.abs(want[..., :3]).max()))
+
+
 def test_one_deep_call_equals_many_shallow_calls(bendy):
     """Size-independent property (main.rs:245-254 accumulates call after call): 2048 samples in one call -- pixel blocks
     of 4x2, hundreds of items per lane -- give the bits of 32 calls of 64 samples."""
@@ -561,11 +591,12 @@ def test_exact_math_helpers_over_all_inputs():
     """bt_device.hpp computes sqrt, 1/sqrt, the hoisted divisions and the camera's small-angle sin/cos with the core of the
     compiler's own IEEE expansions (sqrt_bt, rsqrt_bt, div_refined, sincos_small_bt).  tools/exact_math_check.hip compares
     each of them on the device with the plain expression it replaces, over all 2^32 bit patterns of the argument
-    (2^32 operand pairs for the division); `make` builds it next to the library."""
+    (2^32 operand pairs for the division, once in a narrow and once in the widest exponent window a caller gates on); `make`
+    builds it next to the library."""
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bendy_tracer_amd", "exact_math_check")
     assert os.path.exists(exe), "bendy_tracer_amd/exact_math_check is not built (make -C bendy_tracer_amd/csrc)"
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     lines = [ln for ln in run.stdout.splitlines() if "mismatches" in ln]
-    assert len(lines) == 4 and all(ln.rstrip().endswith("mismatches 0") for ln in lines), run.stdout
+    assert len(lines) == 5 and all(ln.rstrip().endswith("mismatches 0") for ln in lines), run.stdout

@@ -94,6 +94,28 @@ def test_with_frustum(oracle):
     assert d[0] > 0 and d[1] > 0      # u > 0 looks right, v < 0 (top rows) looks up
 
 
+def test_yxz_composition_reproduces_the_camera_matrix_stored_in_scene_json(oracle):
+    """The only reference-held datum with BOTH a Y and an X rotation: scene.json.gz stores its camera's rotation -- written by
+    the reference from `Quat::from_euler(YXZ, 10 deg, -5 deg, 0)` -- as the columns of Ry(10 deg) * Rx(-5 deg).  The closed
+    form that stands in for `Ray::with_frustum`'s quaternion (ray.rs:103-113; glam's YXZ order is recalled, SURVEY App. C) must
+    send (0, 0, -1) where that matrix sends it -- which pins "YXZ = Ry * Rx" and the sign of both angles with data the
+    reference itself wrote (cornell2.json.gz == main.rs:107-214 pins the Y rotation alone)."""
+    import ctypes as C
+    import gzip
+    doc = json.loads(gzip.open(scene_path("scene")).read())
+    cam = next(o for o in doc["objects"]["collection"].values() if o["tag"] == "camera")
+    m = np.array(cam["transform"]["transform_world"][:9], dtype=np.float64).reshape(3, 3).T      # file: columns x, y, z
+    a, b = math.radians(10.0), math.radians(-5.0)
+    ry = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    rx = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+    assert np.abs(m - ry @ rx).max() < 2e-7                       # the stored matrix IS Ry(10) Rx(-5), to f32 rounding
+    assert np.abs(m - rx @ ry).max() > 1e-2                       # ... and not the other order
+    # with_frustum(yfov, xfov, u, v): angles -u * xfov / 2 about Y and -v * yfov / 2 about X; unit fovs: u = -2a, v = -2b
+    d = (C.c_float * 3)()
+    oracle.lib().bto_ray_with_frustum(1.0, 1.0, -2.0 * a, -2.0 * b, d)
+    assert np.abs(np.array(list(d)) - m @ np.array([0.0, 0.0, -1.0])).max() < 3e-7
+
+
 # ---- KAT 2: Sphere::hit (sphere.rs:121-148, 85-119) ------------------------------------------
 def test_sphere_hit(oracle):
     sc = oracle.Scene(json.loads(flat_scene_json()))

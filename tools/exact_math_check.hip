@@ -31,6 +31,11 @@ __global__ void check(unsigned long long *bad, uint32_t *first_bad) {
         const float p = __uint_as_float((h & 0x807fffffu) | ((97u + (h >> 23) % 60u) << 23));
         const float q = __uint_as_float((g & 0x807fffffu) | ((97u + (g >> 23) % 60u) << 23));
         if (!same(div_refined(p, q, refined_rcp(q)), p / q)) { atomicAdd(&bad[2], 1ull); atomicMin(&first_bad[2], b); }
+        // the widest window any caller gates on (bt_api.cpp: clip_max <= 2^60, |q| > 1e-5; the march's rel / size and the sphere
+        // normals: |rel| in [2^-60, 2^60], size in [2^-20, 2^20]): |p| in [2^-60, 2^61), |q| in [2^-20, 2^20)
+        const float pw = __uint_as_float((h & 0x807fffffu) | ((67u + (h >> 23) % 121u) << 23));
+        const float qw = __uint_as_float((g & 0x807fffffu) | ((107u + (g >> 23) % 40u) << 23));
+        if (!same(div_refined(pw, qw, refined_rcp(qw)), pw / qw)) { atomicAdd(&bad[4], 1ull); atomicMin(&first_bad[4], b); }
         float s0, c0, s1, c1;
         sincos_bt(x, s0, c0);
         sincos_small_bt(x, s1, c1);
@@ -41,20 +46,21 @@ __global__ void check(unsigned long long *bad, uint32_t *first_bad) {
 int main() {
     unsigned long long *bad;
     uint32_t *first;
-    if (hipMalloc(&bad, 4 * sizeof(*bad)) != hipSuccess || hipMalloc(&first, 4 * sizeof(*first)) != hipSuccess) return 2;
-    hipMemset(bad, 0, 4 * sizeof(*bad));
-    hipMemset(first, 0xff, 4 * sizeof(*first));
+    if (hipMalloc(&bad, 5 * sizeof(*bad)) != hipSuccess || hipMalloc(&first, 5 * sizeof(*first)) != hipSuccess) return 2;
+    hipMemset(bad, 0, 5 * sizeof(*bad));
+    hipMemset(first, 0xff, 5 * sizeof(*first));
     check<<<256 * 32, 256>>>(bad, first);
     if (hipDeviceSynchronize() != hipSuccess) { std::printf("kernel failed\n"); return 2; }
-    unsigned long long h[4];
-    uint32_t f[4];
+    unsigned long long h[5];
+    uint32_t f[5];
     hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost);
     hipMemcpy(f, first, sizeof(f), hipMemcpyDeviceToHost);
-    const char *name[4] = {"sqrt_bt vs sqrtf (all 2^32 inputs)", "rsqrt_bt vs 1/sqrtf (all 2^32 inputs)",
-                           "div_refined vs p/q (2^32 pairs, |p|,|q| in [2^-30, 2^30))", "sincos_small_bt vs sincos_bt (all 2^32 inputs)"};
+    const char *name[5] = {"sqrt_bt vs sqrtf (all 2^32 inputs)", "rsqrt_bt vs 1/sqrtf (all 2^32 inputs)",
+                           "div_refined vs p/q (2^32 pairs, |p|,|q| in [2^-30, 2^30))", "sincos_small_bt vs sincos_bt (all 2^32 inputs)",
+                           "div_refined vs p/q (|p| in [2^-60, 2^61), |q| in [2^-20, 2^20))"};
     int rc = 0;
-    for (int k = 0; k < 4; ++k) {
-        std::printf("%-62s mismatches %llu", name[k], h[k]);
+    for (int k = 0; k < 5; ++k) {
+        std::printf("%-66s mismatches %llu", name[k], h[k]);
         if (h[k]) { std::printf("  first at bits 0x%08x", f[k]); rc = 1; }
         std::printf("\n");
     }
