@@ -569,11 +569,9 @@ def main():
     if rank == 0:
         k_ms = statistics.mean(kernel_ms)
         seg = statistics.mean(segments)
-        # template arguments <OUTPUT, LENS, QMODE (0 lane-owns-pixel, 1 block queue, 2 streaming queue), RECTS, VOLS>, as
-        # rocprofv3 prints them
-        kernel_name = "bt_render_kernel<0, false, %s, %s, %s>" % (
-            "1" if spp >= 2 else "0",
-            *{"scene": ("false", "false"), "volume": ("false", "true"), "cloud": ("false", "true")}.get(scene_name, ("true", "false")))
+        # template arguments <OUTPUT, LENS, RECTS, VOLS>, as rocprofv3 prints them
+        kernel_name = "bt_render_kernel<0, false, %s, %s>" % (
+            {"scene": ("false", "false"), "volume": ("false", "true"), "cloud": ("false", "true")}.get(scene_name, ("true", "false")))
         roof = {"bound": "valu", "unit": "wave64 VALU instructions per SIMD-cycle", "peak": VALU_PEAK, "achieved": None,
                 "frac": None, "traffic": None, "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "slices": last.slices,
                 "launches_per_step": last.launches, "scratch_bytes": last.scratch_bytes,

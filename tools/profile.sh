@@ -16,15 +16,17 @@ find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 for wl in C3 C2 C4 cornell1080 cloud1080; do
   python3 tools/pmc_collect.py --workload $wl --passes fetch,write,sq,classes,waits --commit $COMMIT --out $OUT/pmc_$wl.json > /dev/null 2>$OUT/pmc_$wl.err || { echo "pmc $wl failed"; tail -3 $OUT/pmc_$wl.err; }
 done
+# one rank's launch of the 8-rank weak-scaling job (bench.py --gpus 8: 1/8 of the tiles at 512 spp) -> key C3_shard8
+python3 tools/pmc_collect.py --workload C3 --shard 0,8 --spp 512 --calls 3 --passes fetch,write,sq,classes,waits --commit $COMMIT --out $OUT/pmc_C3_shard8.json > /dev/null 2>$OUT/pmc_C3_shard8.err || { echo "pmc C3 shard8 failed"; tail -3 $OUT/pmc_C3_shard8.err; }
 python3 - <<PY
 import json, glob, os
 out = {}
 for f in sorted(glob.glob("$OUT/pmc_*.json")):
-    d = json.load(open(f)); out[d["workload"]] = d
+    d = json.load(open(f)); out[d["workload"] + (f"_shard{d['shard']['world']}" if d.get("shard") else "")] = d
 json.dump(out, open("$OUT/pmc_live.json", "w"), indent=1)
 for w, d in out.items():
     x = d["derived"]
-    print(f"{w:12s} sha {d['source_sha']} kernel {d['cli']['kernel_ms_under_profiler']:.3f} ms (under the profiler)  VALU/SIMD-cycle {x['valu_per_simd_cycle']:.3f}  lanes {x['lanes_active']:.3f}  "
+    print(f"{w:14s} sha {d['source_sha']} kernel {d['cli']['kernel_ms_under_profiler']:.3f} ms (under the profiler)  VALU/SIMD-cycle {x['valu_per_simd_cycle']:.3f}  lanes {x['lanes_active']:.3f}  "
           f"mixed-cost {x.get('valu_issue_mixed_frac', 0):.3f} (pure-stream bound {x.get('valu_issue_weighted_frac', 0):.3f})  scalar/CU-cycle {x['scalar_per_cu_cycle']:.3f}  HBM {x['hbm_bytes']/1e9:.3f} GB")
 PY
 head -5 $OUT/kernel_stats.csv
