@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): launch shapes against the oracle -- random frame sizes (up to 1920x1080), 1 ... 48 samples,
-Subsample 1 ... 3, full frames and rank shards, on the three scene classes; whatever bt_api.cpp picks (slices, tiles per
-workgroup, launches) must give the oracle's bits.  usage: python3 tools/fuzz_shapes.py [n_cases] [seed]"""
+Subsample 1 ... 3, full frames and rank shards, on the three scene classes; whatever bt_api.cpp picks (slices, launches), and
+every pinned block shape, must give the oracle's bits.  usage: python3 tools/fuzz_shapes.py [n_cases] [seed]"""
 import json
 import os
 import random
@@ -31,7 +31,8 @@ for case in range(n):
     spp = rng.choice([1, 1, 2, 3, 5, 8, 13, 16, 24, 48]) if not big else rng.choice([1, 2, 4])
     sub = rng.choice([0, 0, 2, 3]) if spp <= 8 else 0
     world = rng.choice([1, 1, 1, 2, 3])
-    sc, cam = gpu_scene(bendy, name, w, h)
+    pin = rng.choice([None, None, None, 1, 2, 4, 8, 16, 32])      # bt_tuning.slices: every block shape, not only the automatic one
+    sc, cam = gpu_scene(bendy, name, w, h, tuning={"slices": pin} if pin else None)
     tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
     rc = bendy.RenderConfig.with_samples_subsample(spp, bendy.Subsample(sub)) if sub else bendy.RenderConfig.with_samples(spp)
     if world == 1:
