@@ -455,6 +455,12 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             while (S < 32 && (uint64_t)grid * (2 * S) * 4 <= 5 * target && T / (2 * S) >= 8) S *= 2;
             while (S < 32 && (uint64_t)grid * S * 2 < target && T / (2 * S) >= 4) S *= 2;
             while (S < 32 && (uint64_t)grid * 4 * S < 2 * wave_slots && T / (2 * S) >= 1) S *= 2;
+            // Sphere-only scenes (cheaper items, eight waves per SIMD) want more, smaller workgroups on small frames than the rect
+            // builds: up to ~7 500 of them while a lane still gets a whole item (profiles/r04j: scene.json 768 x 512 with the
+            // reference CLI's 1 sample x Subpixel(2): S = 2 -> 4, 0.129 -> 0.119 ms; 8 rays: 0.197 -> 0.167; 1280 x 720 x 4:
+            // 0.212 -> 0.184; the Cornell boxes lose with the same change)
+            if (!P.any_rects)
+                while (S < 32 && (uint64_t)grid * (2 * S) <= 30ull * (uint64_t)s->n_cu && 256 * T / (2 * S) >= 256) S *= 2;
         }
         return S;
     };
