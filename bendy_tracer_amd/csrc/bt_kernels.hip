@@ -35,6 +35,8 @@
 // r04e, r04f).
 #include "bt_device.hpp"
 
+#define BT_SUM_BATCH 8             // parked values a lane of the summing wave has in flight (16: no difference, profiles/r04k)
+
 // Developer build (-DBT_PROFILE): s_memtime stamps around the sections of the render loop, summed per wave into
 // counters[2..]; shares of wave cycles are printed by bt_scene_last_stats.  Not part of the product build.
 // Developer build (-DBT_LANESTAT, implies the 12 counters of BT_PROFILE): per wave-iteration popcounts of what the lanes
@@ -132,12 +134,12 @@ BT_DEV void sum_block(const BtLaunch &P, const BlockGeom &g, uint32_t b, uint32_
             const Parked *s = src + q;
             V3 sum = mk(o[0], o[1], o[2]);
             uint32_t kk = 0;
-            for (; kk + 8 <= T; kk += 8) {             // eight loads in flight, additions strictly in order
-                Parked v[8];
+            for (; kk + BT_SUM_BATCH <= T; kk += BT_SUM_BATCH) {   // BT_SUM_BATCH loads in flight, additions strictly in order
+                Parked v[BT_SUM_BATCH];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = s[(size_t)(kk + j) * pxb];
+                for (int j = 0; j < BT_SUM_BATCH; ++j) v[j] = s[(size_t)(kk + j) * pxb];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
+                for (int j = 0; j < BT_SUM_BATCH; ++j) sum = sum + mk(v[j].x, v[j].y, v[j].z);
             }
             for (; kk < T; ++kk) {
                 const Parked v = s[(size_t)kk * pxb];

@@ -16,8 +16,10 @@ find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 for wl in C3 C2 C4 cornell1080 cloud1080; do
   python3 tools/pmc_collect.py --workload $wl --passes fetch,write,sq,classes,waits --commit $COMMIT --out $OUT/pmc_$wl.json > /dev/null 2>$OUT/pmc_$wl.err || { echo "pmc $wl failed"; tail -3 $OUT/pmc_$wl.err; }
 done
-# one rank's launch of the 8-rank weak-scaling job (bench.py --gpus 8: 1/8 of the tiles at 512 spp) -> key C3_shard8
-python3 tools/pmc_collect.py --workload C3 --shard 0,8 --spp 512 --calls 3 --passes fetch,write,sq,classes,waits --commit $COMMIT --out $OUT/pmc_C3_shard8.json > /dev/null 2>$OUT/pmc_C3_shard8.err || { echo "pmc C3 shard8 failed"; tail -3 $OUT/pmc_C3_shard8.err; }
+# one rank's launch of the N-rank weak-scaling jobs (bench.py --gpus N: 1/N of the tiles at 64 N spp) -> keys C3_shard2 / 4 / 8
+for n in 2 4 8; do
+  python3 tools/pmc_collect.py --workload C3 --shard 0,$n --spp $((64 * n)) --calls 3 --passes fetch,write,sq,classes,waits --commit $COMMIT --out $OUT/pmc_C3_shard$n.json > /dev/null 2>$OUT/pmc_C3_shard$n.err || { echo "pmc C3 shard $n failed"; tail -3 $OUT/pmc_C3_shard$n.err; }
+done
 python3 - <<PY
 import json, glob, os
 out = {}
