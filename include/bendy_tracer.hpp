@@ -87,6 +87,7 @@ class Scene {                                           // scene/mod.rs:84-146
         return s;
     }
     bt_stats last_stats() const { bt_stats st{}; check(bt_scene_last_stats(h_, &st)); return st; }
+    void trim() { check(bt_scene_trim(h_)); }           // returns the handle's scratch / cached frame to the device (not in the reference)
     bt_scene *handle() const { return h_; }
 
   private:

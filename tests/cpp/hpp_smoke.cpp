@@ -22,6 +22,7 @@ int main(int argc, char **argv) {
     const unsigned w = 48, h = 27;
     scene.set_camera_aspect(*camera, (float)w / h);
     if (scene.to_json().find("\"roots\"") == std::string::npos) return 6;
+    scene.trim();                                        // nothing held yet: a no-op that must not fail (with or without a GPU)
     bendy::Tracer tracer = bendy::Tracer::with_config({.chunks_x = 8, .chunks_y = 4});
     bendy::Buffer buffer(w, h, bendy::ColorSpace::SRgb);
     if (tracer.render(scene, *camera, bendy::RenderConfig::with_samples(0), buffer) != bendy::Status::Done) return 7;
@@ -39,6 +40,7 @@ int main(int argc, char **argv) {
     auto p = buffer.preview();
     std::fwrite(p.data(), 1, p.size(), f);
     std::fclose(f);
+    scene.trim();                                        // returns the scratch of the renders above
     std::printf("ok samples=%u\n", buffer.samples());
     return 0;
 }
