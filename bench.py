@@ -258,7 +258,7 @@ def other_configs(b, torch, steps=3, pmc_by_config=None):
         out[name] = {"workload": f"{scene_name}.json.gz {w}x{h}x{spp}spp", "value": round(w * h * spp / ms / 1e3, 1),
                      "unit": "Msamples/s", "ms_per_render": round(ms, 4), "kernel_ms": round(k_ms, 4),
                      "segments_per_sample": round(st.segments / st.samples, 4), "launches": st.launches,
-                     "slices": st.slices, "scratch_bytes": st.scratch_bytes}
+                     "slices": st.slices, "packed": bool(st.packed), "scratch_bytes": st.scratch_bytes}
         if pmc_by_config and pmc_by_config.get(name):
             out[name]["roofline"] = {"bound": "valu", "peak": VALU_PEAK, **pmc_fractions(pmc_by_config[name], k_ms)}
         del buf, sc
@@ -288,7 +288,8 @@ def other_configs(b, torch, steps=3, pmc_by_config=None):
     out["interactive_default"] = {"workload": "scene.json.gz 768x512, 1 sample x Subpixel(2) per call (the reference CLI's defaults)",
                                   "value": round(w * h * 4 / ms / 1e3, 1), "unit": "Msamples/s", "ms_per_call_pipelined": round(ms, 4),
                                   "ms_per_call_synchronised": round(statistics.median(lat), 4),
-                                  "kernel_ms": round(sc.last_stats().kernel_ms, 4), "slices": sc.last_stats().slices}
+                                  "kernel_ms": round(sc.last_stats().kernel_ms, 4), "slices": sc.last_stats().slices,
+                                  "packed": bool(sc.last_stats().packed)}
     return out
 
 
@@ -569,11 +570,13 @@ def main():
     if rank == 0:
         k_ms = statistics.mean(kernel_ms)
         seg = statistics.mean(segments)
-        # template arguments <OUTPUT, LENS, RECTS, VOLS>, as rocprofv3 prints them
-        kernel_name = "bt_render_kernel<0, false, %s, %s>" % (
-            {"scene": ("false", "false"), "volume": ("false", "true"), "cloud": ("false", "true")}.get(scene_name, ("true", "false")))
+        # template arguments <OUTPUT, LENS, RECTS, VOLS, PACKED>, as rocprofv3 prints them
+        kernel_name = "bt_render_kernel<0, false, %s, %s, %s>" % (
+            {"scene": ("false", "false"), "volume": ("false", "true"), "cloud": ("false", "true")}.get(scene_name, ("true", "false"))
+            + ("true" if last.packed else "false",))
         roof = {"bound": "valu", "unit": "wave64 VALU instructions per SIMD-cycle", "peak": VALU_PEAK, "achieved": None,
                 "frac": None, "traffic": None, "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "slices": last.slices,
+                "workgroups": last.workgroups, "packed": bool(last.packed),
                 "launches_per_step": last.launches, "scratch_bytes": last.scratch_bytes,
                 "render_stream_ms_per_step_timed_region": round(statistics.mean(step_ms), 4),
                 "segments_per_launch": int(seg), "segments_per_sample": round(seg / (my_pixels * spp), 4)}

@@ -123,11 +123,12 @@ class _CRenderConfig(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("pixels", C.c_uint64), ("kernel_ms", C.c_float),
                 ("lens_steps", C.c_uint64), ("slices", C.c_uint32), ("launches", C.c_uint32),
-                ("scratch_bytes", C.c_uint64), ("parked_bytes", C.c_uint64), ("reserved", C.c_uint32 * 2)]
+                ("scratch_bytes", C.c_uint64), ("parked_bytes", C.c_uint64), ("workgroups", C.c_uint32), ("packed", C.c_uint32)]
 
 
 class _CTuning(C.Structure):  # include/bendy_hip.h `bt_tuning`
-    _fields_ = [("slices", C.c_uint32), ("phase_vote", C.c_int32), ("scratch_cap_bytes", C.c_uint64)]
+    _fields_ = [("slices", C.c_uint32), ("phase_vote", C.c_int32), ("scratch_cap_bytes", C.c_uint64), ("packed", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class _CLens(C.Structure):
@@ -308,7 +309,7 @@ class Scene:
 
     def set_tuning(self, **knobs):
         """bt_scene_set_tuning: pins launch-shape knobs of this handle (tests and A/B tools; none of them changes a
-        pixel).  Keywords = fields of `bt_tuning` (slices, phase_vote, scratch_cap_bytes);
+        pixel).  Keywords = fields of `bt_tuning` (slices, phase_vote, scratch_cap_bytes, packed);
         fields not named keep their current value; no keywords = defaults."""
         t = _CTuning()
         if not knobs:
@@ -327,9 +328,9 @@ class Scene:
         return {k: getattr(t, k) for k, _ in _CTuning._fields_}
 
     def tuning_from_env(self, environ=None):
-        """Developer convenience for tools/ and tests/: BT_SLICES, BT_PHASE_VOTE, BT_SCRATCH_CAP -> set_tuning().  The library itself never reads the environment."""
+        """Developer convenience for tools/ and tests/: BT_SLICES, BT_PHASE_VOTE, BT_SCRATCH_CAP, BT_PACKED -> set_tuning().  The library itself never reads the environment."""
         env = os.environ if environ is None else environ
-        names = {"BT_SLICES": "slices", "BT_PHASE_VOTE": "phase_vote", "BT_SCRATCH_CAP": "scratch_cap_bytes"}
+        names = {"BT_SLICES": "slices", "BT_PHASE_VOTE": "phase_vote", "BT_SCRATCH_CAP": "scratch_cap_bytes", "BT_PACKED": "packed"}
         knobs = {f: int(env[e]) for e, f in names.items() if env.get(e) not in (None, "", "-")}
         if knobs:
             self.set_tuning(**knobs)

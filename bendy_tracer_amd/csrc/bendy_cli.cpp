@@ -175,7 +175,7 @@ int main(int argc, char **argv) {
         auto env = [&](const char *name, auto &field) {
             if (const char *e = std::getenv(name)) { field = (std::remove_reference_t<decltype(field)>)std::strtoll(e, nullptr, 10); any = true; }
         };
-        env("BT_SLICES", t.slices); env("BT_PHASE_VOTE", t.phase_vote); env("BT_SCRATCH_CAP", t.scratch_cap_bytes);
+        env("BT_SLICES", t.slices); env("BT_PHASE_VOTE", t.phase_vote); env("BT_SCRATCH_CAP", t.scratch_cap_bytes); env("BT_PACKED", t.packed);
         if (any) check(bt_scene_set_tuning(scene, &t), "bt_scene_set_tuning");
     }
 
@@ -221,9 +221,9 @@ int main(int argc, char **argv) {
             bt_stats cs{};
             bt_scene_last_stats(scene, &cs);
             char row[256];
-            std::snprintf(row, sizeof row, "%s{\"kernel_ms\": %.5f, \"segments\": %llu, \"samples\": %llu, \"pixels\": %llu, \"slices\": %u}",
+            std::snprintf(row, sizeof row, "%s{\"kernel_ms\": %.5f, \"segments\": %llu, \"samples\": %llu, \"pixels\": %llu, \"slices\": %u, \"packed\": %u}",
                           per_call.empty() ? "" : ", ", cs.kernel_ms, (unsigned long long)cs.segments,
-                          (unsigned long long)cs.samples, (unsigned long long)cs.pixels, cs.slices);
+                          (unsigned long long)cs.samples, (unsigned long long)cs.pixels, cs.slices, cs.packed);
             per_call += row;
         }
         if (!args.quiet)

@@ -404,6 +404,9 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         if (lds_bytes + P.vbox_lds_bytes > 32 * 1024) P.vbox_lds_bytes = 0;          // big scenes keep the per-step arithmetic
         lds_bytes += P.vbox_lds_bytes;
     }
+#ifdef BT_LDS_PAD                                   // developer build: unused LDS per workgroup, to time lower occupancies
+    lds_bytes += BT_LDS_PAD;
+#endif
     // the launch should hold >= 4 x 20 waves per CU (tuned on the MI355X's 256 CUs as "4 * 5120 waves", round 1d)
     const uint64_t wave_slots = (uint64_t)s->n_cu * 20;
     auto ensure_scratch = [&](uint64_t need) -> bool {
@@ -465,19 +468,57 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         return S;
     };
     P.slices = (int32_t)pick((uint64_t)chunk * nn);
+    // a workgroup counts its path segments in 32 bits (bt_stats.segments): keep its work items x the longest possible path
+    // below 2^32 -- only a pinned launch shape (bt_tuning.slices with an enormous scratch cap) can get near
+    const uint64_t longest = ((uint64_t)P.max_bounces + 2) * ((uint64_t)P.max_volume_bounces + 3) + (P.lens_on ? 2 : 0);
+    const uint64_t items_max = std::max<uint64_t>(1, 0xffffffffull / longest);
     {
-        // a workgroup counts its path segments in 32 bits (bt_stats.segments): keep its work items x the longest possible path
-        // below 2^32 -- only a pinned launch shape (bt_tuning.slices with an enormous scratch cap) can get near
-        const uint64_t longest = ((uint64_t)P.max_bounces + 2) * ((uint64_t)P.max_volume_bounces + 3) + (P.lens_on ? 2 : 0);
-        const uint64_t items_max = std::max<uint64_t>(1, 0xffffffffull / longest);
         const uint64_t pxb = 256u / (uint32_t)P.slices;
         if (pxb * chunk * nn > items_max) chunk = (uint32_t)std::max<uint64_t>(1, items_max / (pxb * nn));
     }
+    // Packed launch: when the whole render is one launch of at most a few generations of workgroups, ONE generation -- a workgroup
+    // per workgroup slot of the GPU, each owning every n_workgroups-th block of 8 pixels behind one queue -- ends with one drain
+    // of its longest paths instead of one per generation.
+    P.wg_blocks = 1;
+    P.wg_blocks_rem = 0;
+    P.n_workgroups = 0;
+    P.log_rows = 0;
+    P.row_mask = 0xffffffffu;
+    // workgroup slots of the GPU: 7 per CU by the builds' __launch_bounds__ (72 VGPRs), fewer when the scene tables are large
+    // (160 KB of LDS per CU, allocated in 2 KB steps here to stay on the safe side)
+    const uint32_t wg_lds = (uint32_t)((lds_bytes + 64 + 2047) & ~(size_t)2047);
+    const uint32_t wg_slots = (uint32_t)s->n_cu * std::max(1u, std::min(7u, 160u * 1024u / wg_lds));
+    const uint64_t T_launch = (uint64_t)chunk * nn;
+    // Measured (profiles/r04s: 512 x 512 ... 1920 x 1080 frames, 1 ... 32 rays per pixel, three scene classes): packing pays
+    // between ~1 and ~24 work items per lane of the GPU (scene.json 768 x 512 x 4: 0.121 -> 0.09 ms); deeper launches overlap
+    // their drains with other workgroups' work and lose 5 - 20 % when packed, emptier ones do not fill the slots
+    const uint64_t items_all = px_launch * T_launch, lanes_all = (uint64_t)wg_slots * 256;
+    const bool pack = tune.packed > 0 || (tune.packed < 0 && items_all > lanes_all && items_all <= 24 * lanes_all);
+    if (pack && chunk == (uint32_t)P.samples && output == 0 && !P.lens_on) {      // (the packed builds: Full output, no lens)
+        // blocks of ~64 / T pixels: one wave's take from the queue is one block's samples (coherent camera rays)
+        uint32_t S = 4;
+        while (S < 32 && S < 4 * T_launch) S *= 2;
+        if (tune.slices) S = tune.slices;
+        const uint64_t blocks = (uint64_t)grid * S, per_wg = (blocks + wg_slots - 1) / wg_slots;
+        uint32_t log_rows = 0;                                   // T padded to a power of two: rows of a block in the queue
+        while ((1ull << log_rows) < T_launch) log_rows += 1;
+        const uint64_t wg_items = (per_wg * (256u / S)) << log_rows;
+        const uint64_t need = (uint64_t)wg_slots * wg_items * 3 * sizeof(float);
+        if (blocks > wg_slots && blocks <= 0x7fffffffu && wg_items <= items_max &&
+            (need <= s->scratch_bytes || ensure_scratch(need))) {
+            P.slices = (int32_t)S;
+            P.n_workgroups = wg_slots;
+            P.wg_blocks = (uint32_t)per_wg;
+            P.wg_blocks_rem = (uint32_t)(blocks - (per_wg - 1) * wg_slots);
+            P.log_rows = log_rows;
+            P.row_mask = (1u << log_rows) - 1u;
+        } else if (!s->d_scratch && !ensure_scratch(per_sample * chunk)) {
+            return set_error(BT_ERR_DEVICE, "no device memory for the parked samples");
+        }
+        P.scratch = s->d_scratch;
+    }
     const uint64_t parked_bytes = px_launch * T_all * 3 * sizeof(float);
 
-#ifdef BT_LDS_PAD                                   // developer build: unused LDS per workgroup, to time lower occupancies
-    lds_bytes += BT_LDS_PAD;
-#endif
     if (lds_bytes > 158 * 1024)
         return set_error(BT_ERR_INVALID_ARG, "scene tables (" + std::to_string(s->flat.lds_bytes()) +
                                                  " bytes) exceed the 160 KB of LDS of a gfx950 CU");
@@ -519,6 +560,8 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     s->last.kernel_ms = 0.0f;
     s->last.slices = (uint32_t)P.slices;
     s->last.launches = launches;
+    s->last.packed = P.wg_blocks > 1 ? 1u : 0u;
+    s->last.workgroups = P.wg_blocks > 1 ? P.n_workgroups : grid * (uint32_t)P.slices;
     s->last.scratch_bytes = s->scratch_bytes;
     s->last.parked_bytes = parked_bytes;
     s->stats_pending = true;
@@ -555,6 +598,7 @@ void bt_tuning_default(bt_tuning *t) {
     if (!t) return;
     std::memset(t, 0, sizeof *t);
     t->phase_vote = -1;
+    t->packed = -1;
 }
 
 int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
@@ -568,6 +612,7 @@ int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
         return set_error(BT_ERR_INVALID_ARG, "bt_tuning.slices must be 0 (auto), 1, 2, 4, 8, 16 or 32");
     if (t->phase_vote < -1 || t->phase_vote > 64)
         return set_error(BT_ERR_INVALID_ARG, "bt_tuning.phase_vote must be -1 .. 64");
+    if (t->packed < -1 || t->packed > 1) return set_error(BT_ERR_INVALID_ARG, "bt_tuning.packed must be -1, 0 or 1");
     scene->tuning = *t;
     return 0;
 }

@@ -9,10 +9,13 @@
 //   march (volume.rs) -> `+=` into the RGBA32F accumulator (buffer.rs:159-178).
 //
 // Mapping to the hardware:
-//   * a workgroup owns a block of 256/S pixels (S = 1..32; or 2 / 4 whole tiles for very shallow launches) and all of
-//     their samples in this launch.  The block's (pixel, sample) pairs are a work queue in LDS: a lane whose path has
-//     ended takes the next pair, every sample's value is parked in HBM and the last wave of the workgroup adds the
-//     parked values to the frame in sample order -- the reference's per-pixel summation order, no atomics on the frame;
+//   * a workgroup owns a block of 256/S pixels (S = 1..32) and all of their samples in this launch.  The block's
+//     (pixel, sample) pairs are a work queue in LDS: a lane whose path has ended takes the next pair, every sample's
+//     value is parked in HBM and the last wave of the workgroup adds the parked values to the frame in sample order --
+//     the reference's per-pixel summation order, no atomics on the frame;
+//   * a launch of only a few work items per lane of the GPU is PACKED instead: one workgroup per workgroup slot, each
+//     owning every k-th pixel block behind one queue, so that the GPU drains its longest paths once, not once per
+//     generation of workgroups (own builds, template flag PACKED);
 //   * in the sphere-only builds a wave votes every iteration whether it runs the camera event or the scatter / volume
 //     events; the lanes of the other kind keep their state for the next iteration (phase voting);
 //   * every loop iteration is TRACE (one path segment, all lanes) followed by exactly ONE random event per lane --
@@ -182,6 +185,39 @@ BT_DEV void sum_block(const BtLaunch &P, const BlockGeom &g, uint32_t b, uint32_
     }
 }
 
+
+// A workgroup of a packed launch (BtLaunch::wg_blocks > 1) owns the blocks first, first + stride, ...: `n` of them, parked
+// back to back.  All its threads sum, one pixel each at a time, BT_SUM_BATCH parked values in flight, additions strictly in
+// sample order.
+BT_DEV void sum_blocks(const BtLaunch &P, const BlockGeom &g, uint32_t first, uint32_t stride, uint32_t n, uint32_t T,
+                       const Parked *src, uint32_t thread, uint32_t n_threads) {
+    const uint32_t LOG_ROWS = P.log_rows;              // a block's samples are padded to 2^log_rows rows of pxb parked values
+    for (uint32_t p = thread; p < (n << g.LOG_PXB); p += n_threads) {
+        const uint32_t j = p >> g.LOG_PXB, q = p & (g.pxb - 1u);
+        const BlockRef B = block_ref(P, g, first + j * stride);
+        const PixelRef r = pixel_of(P, g, B, q);
+        if (!r.in_frame) continue;
+        float *o = out_of(P, B, r);
+        const Parked *s = src + ((size_t)j << (LOG_ROWS + g.LOG_PXB)) + q;
+        V3 sum = mk(o[0], o[1], o[2]);
+        uint32_t kk = 0;
+        for (; kk + BT_SUM_BATCH <= T; kk += BT_SUM_BATCH) {
+            Parked v[BT_SUM_BATCH];
+#pragma unroll
+            for (int u = 0; u < BT_SUM_BATCH; ++u) v[u] = s[(size_t)(kk + u) << g.LOG_PXB];
+#pragma unroll
+            for (int u = 0; u < BT_SUM_BATCH; ++u) sum = sum + mk(v[u].x, v[u].y, v[u].z);
+        }
+        for (; kk < T; ++kk) {
+            const Parked v = s[(size_t)kk << g.LOG_PXB];
+            sum = sum + mk(v.x, v.y, v.z);
+        }
+        o[0] = sum.x;
+        o[1] = sum.y;
+        o[2] = sum.z;
+    }
+}
+
 } // namespace
 
 // --------------------------------------------------------------------------------------------
@@ -209,7 +245,9 @@ BT_DEV void sum_block(const BtLaunch &P, const BlockGeom &g, uint32_t b, uint32_
 #endif
 // RECTS = false: sphere-only scenes (scene.json, volume.json, cloud.json) run a build without any rect / cuboid code.
 // VOLS = false: no sphere carries a volume (scene.json, the Cornell boxes): the march and Volume::shade drop out.
-template <int OUTPUT, bool LENS, bool RECTS, bool VOLS>
+// PACKED = true: the build for packed launches (BtLaunch::wg_blocks > 1; Full output without the lens only), so that the
+// other builds carry none of its code -- as a run-time switch it cost C3 4 % (profiles/r04u).
+template <int OUTPUT, bool LENS, bool RECTS, bool VOLS, bool PACKED>
 __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : (VOLS ? BT_WAVES_PER_SIMD_VOLS : BT_WAVES_PER_SIMD))) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_waves_done;      // block queue: waves of this workgroup that have parked all their samples
@@ -285,9 +323,18 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     const uint32_t nn = (uint32_t)(P.subsample_n * P.subsample_n);
     const uint32_t T = (uint32_t)P.samples * nn;       // samples per pixel in this launch
     const uint32_t sample0 = P.sample_base * nn;
-    const uint32_t n_items = pxb * T;                  // work items of one block
-    // block queue: this workgroup's one block (launch order = blockIdx.x)
+    // block queue: this workgroup's one block (launch order = blockIdx.x) -- or, in a packed launch (wg_blocks > 1: gridDim.x
+    // workgroups for the launch's blocks), the blocks blockIdx.x, blockIdx.x + gridDim.x, ... behind ONE queue: item
+    // i = ((j << log_rows | k) << LOG_PXB) + pixel for sample k of the workgroup's j-th block (rows k >= T are holes: T is
+    // padded to a power of two so that neither j nor k costs a division)
+    constexpr bool packed = PACKED;
+    const uint32_t my_blocks = packed ? P.wg_blocks - (blockIdx.x < P.wg_blocks_rem ? 0u : 1u) : 1u;
+    const uint32_t n_items = packed ? (my_blocks << (P.log_rows + LOG_PXB)) : pxb * T;      // work items of this workgroup
     const BlockRef B_own = block_ref(P, G, blockIdx.x);
+    // where this workgroup parks: every workgroup of a packed launch has room for wg_blocks blocks
+    auto park = [&]() -> Parked * {
+        return (Parked *)P.scratch + (size_t)blockIdx.x * (packed ? (size_t)P.wg_blocks << (P.log_rows + LOG_PXB) : (size_t)n_items);
+    };
 
     // the lane's current work item: pixel_index keys the Philox counter; park_i = the item's number i = k * pxb + pixel in
     // the block, where its value is parked (+ the workgroup's base; the sample number k comes out of it, one register less
@@ -328,7 +375,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         } else {
             value = first;
         }
-        ((Parked *)P.scratch + (size_t)blockIdx.x * n_items)[park_i] = Parked{value.x, value.y, value.z};
+        park()[park_i] = Parked{value.x, value.y, value.z};
     };
 
     BT_PROF_DECL;
@@ -493,10 +540,17 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                     const uint32_t i = base + lanes_below(need);
                     if (i >= n_items) break;                              // the block's samples are all taken
                     park_i = i;                                           // (+ the workgroup's base, see finish_sample)
-                    const PixelRef r = pixel_of(P, G, B_own, i & (pxb - 1u));
+                    BlockRef B_i = B_own;
+                    bool hole = false;
+                    if (packed) {                                         // which of the workgroup's blocks, which row of it
+                        const uint32_t row = i >> LOG_PXB;
+                        B_i = block_ref(P, G, blockIdx.x + (row >> P.log_rows) * gridDim.x);
+                        hole = (row & P.row_mask) >= T;
+                    }
+                    const PixelRef r = pixel_of(P, G, B_i, i & (pxb - 1u));
                     px = r.px;
                     py = r.py;
-                    if (!r.in_frame) {
+                    if (!r.in_frame || hole) {
                         pending = true;                                   // pixel outside the frame (edge tile): skip it
                         continue;
                     }
@@ -510,7 +564,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         BT_LS(5, __ballot(ev == EV_GLASS)); BT_LS(6, __ballot(ev == EV_VOLUME));
         // ---- the lane's one random event of this iteration (numerics contract N6) ----
         // block queue: the item's sample number comes out of its item number (one register less than keeping both)
-        const uint32_t k_now = park_i >> LOG_PXB;
+        const uint32_t k_now = packed ? (park_i >> LOG_PXB) & P.row_mask : park_i >> LOG_PXB;
         const uint32_t sample_index = sample0 + k_now;
         const U4 u = philox(pixel_index, sample_index, ev == EV_GEN ? 0u : event, 0u, P.seed_lo, P.seed_hi);
         // slots of the two angular draws: Metallic [0],[1]; Glass [1],[2]; everything else [2],[3]
@@ -726,17 +780,27 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         for (int off = 32; off > 0; off >>= 1) sg += __shfl_xor(sg, off, 64);
         if (lane == 0 && sg) atomicAdd(&s_segments, sg);              // LDS; ahead of this wave's s_waves_done below
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    uint32_t arrived = 0;
-    if (lane == 0) arrived = atomicAdd(&s_waves_done, 1u);
-    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
-    if (arrived == (blockDim.x >> 6) - 1u) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (P.counters && lane == 0) {
+    if (packed) {
+        // one generation of workgroups: nobody waits for this workgroup's wave slots, so its waves meet at a barrier and sum together
+        __syncthreads();
+        if (P.counters && threadIdx.x == 0) {
             const uint32_t total = *(volatile uint32_t *)&s_segments;
             if (total) atomicAdd(&P.counters[0], (unsigned long long)total);
         }
-        sum_block(P, G, blockIdx.x, T, (const Parked *)P.scratch + (size_t)blockIdx.x * n_items, lane);
+        sum_blocks(P, G, blockIdx.x, gridDim.x, my_blocks, T, park(), threadIdx.x, blockDim.x);
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t arrived = 0;
+        if (lane == 0) arrived = atomicAdd(&s_waves_done, 1u);
+        arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+        if (arrived == (blockDim.x >> 6) - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (P.counters && lane == 0) {
+                const uint32_t total = *(volatile uint32_t *)&s_segments;
+                if (total) atomicAdd(&P.counters[0], (unsigned long long)total);
+            }
+            sum_block(P, G, blockIdx.x, T, park(), lane);
+        }
     }
     if (P.counters) {
         if (LENS) {
@@ -836,30 +900,37 @@ __global__ __launch_bounds__(256) void bt_preview_kernel(const float4 *rgba, uin
 extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream) {
     // grid = tiles to render; a tile is P->slices workgroups (see the mapping in the kernel)
-    dim3 g(grid * (unsigned)P->slices), b(256);
+    const bool packed = P->wg_blocks > 1;          // bt_api.cpp packs Full-output launches without the lens only
+    if (packed && (output != 0 || P->lens_on)) return hipErrorInvalidValue;
+    dim3 g(packed ? P->n_workgroups : grid * (unsigned)P->slices), b(256);
     // scene classes: bit 0 = some sphere carries a volume (volume.json, cloud.json), bit 1 = rects / cuboids present
     // (the Cornell boxes); scene.json is class 0
     const int cls = (P->any_rects ? 2 : 0) | (P->any_volumes ? 1 : 0);
     // scene tables beyond the default 64 KB of dynamic LDS (hundreds of objects): gfx950 has 160 KB per CU, the limit
     // has to be raised per kernel; one workgroup per CU is then all that fits
-#define BT_LAUNCH(O, L, R, V)                                                                                    \
+#define BT_LAUNCH(O, L, R, V, K)                                                                                 \
     do {                                                                                                         \
         if (lds_bytes > 48 * 1024)                                                                               \
-            (void)hipFuncSetAttribute((const void *)bt_render_kernel<O, L, R, V>,                                \
+            (void)hipFuncSetAttribute((const void *)bt_render_kernel<O, L, R, V, K>,                             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
-        hipLaunchKernelGGL((bt_render_kernel<O, L, R, V>), g, b, lds_bytes, stream, *P);                         \
+        hipLaunchKernelGGL((bt_render_kernel<O, L, R, V, K>), g, b, lds_bytes, stream, *P);                      \
     } while (0)
 #define BT_LAUNCH_OUT(L, R, V)                                                                                   \
     switch (output) {                                                                                            \
-    case 0: BT_LAUNCH(0, L, R, V); break;                                                                        \
-    case 1: BT_LAUNCH(1, L, R, V); break;                                                                        \
-    case 2: BT_LAUNCH(2, L, R, V); break;                                                                        \
-    default: BT_LAUNCH(3, L, R, V); break;                                                                       \
+    case 0: BT_LAUNCH(0, L, R, V, false); break;                                                                 \
+    case 1: BT_LAUNCH(1, L, R, V, false); break;                                                                 \
+    case 2: BT_LAUNCH(2, L, R, V, false); break;                                                                 \
+    default: BT_LAUNCH(3, L, R, V, false); break;                                                                \
     }
 #define BT_LAUNCH_CLASS(L)                                                                                       \
     if (cls == 3) { BT_LAUNCH_OUT(L, true, true) } else if (cls == 2) { BT_LAUNCH_OUT(L, true, false) }            \
     else if (cls == 1) { BT_LAUNCH_OUT(L, false, true) } else { BT_LAUNCH_OUT(L, false, false) }
-    if (P->lens_on) {
+    if (packed) {
+        if (cls == 3) BT_LAUNCH(0, false, true, true, true);
+        else if (cls == 2) BT_LAUNCH(0, false, true, false, true);
+        else if (cls == 1) BT_LAUNCH(0, false, false, true, true);
+        else BT_LAUNCH(0, false, false, false, true);
+    } else if (P->lens_on) {
         BT_LAUNCH_CLASS(true)
     } else {
         BT_LAUNCH_CLASS(false)

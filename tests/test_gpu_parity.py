@@ -290,6 +290,78 @@ def test_shallow_launches(bendy, oracle, name, samples, n, world):
         assert np.array_equal(out.numpy(), it)
 
 
+def _workgroup_slots():
+    import torch
+    return torch.cuda.get_device_properties(0).multi_processor_count * 7      # bt_api.cpp: 7 workgroups per CU for small scene tables
+
+
+@pytest.mark.parametrize("world", [1, 3])
+@pytest.mark.parametrize("name,w,h,samples,n,slices", [
+    ("cornell2", 330, 200, 3, 0, 0),     # 3 rays per pixel: rows padded to 4 (holes in the queue), block shape left to the library
+    ("scene", 400, 260, 1, 2, 16),       # the reference's interactive pattern, 4 x 4 blocks
+    ("volume", 330, 200, 5, 0, 32),      # 5 -> 8 rows
+    ("cloud", 512, 300, 1, 0, 4),        # one ray per pixel, whole quadrants
+    ("cornell", 330, 200, 2, 3, 8),      # 18 -> 32 rows, ragged right / bottom tiles
+])
+def test_packed_launches(bendy, oracle, name, w, h, samples, n, slices, world):
+    """bt_tuning.packed = 1: one workgroup per workgroup slot of the GPU, each owning every k-th pixel block behind ONE queue
+    (rows of a block padded to a power of two), all its waves summing the parked values at the end -- scheduling only, the
+    oracle's bits in the full-frame and in the sharded layout."""
+    import torch
+    it, seg = oracle_render(oracle, name, w, h, samples, n=n, threads=16)
+    tuning = {"packed": 1}
+    if slices:
+        tuning["slices"] = slices
+    sc, cam = gpu_scene(bendy, name, w, h, tuning=tuning)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    rc = bendy.RenderConfig.with_samples_subsample(samples, bendy.Subsample(n))
+    tiles = -(-w // 16) * -(-h // 16)
+    if world == 1:
+        buf = bendy.Buffer.new(w, h)
+        tr.render(sc, cam, rc, buf)
+        torch.cuda.synchronize()
+        st = sc.last_stats()
+        assert st.segments == seg and np.array_equal(buf.numpy(), it)
+    else:
+        shards = []
+        for r in range(world):
+            sh = bendy.new_shard(w, h, world)
+            tr.render_shard(sc, cam, rc, sh, w, h, r, world)
+            shards.append(sh)
+        out = bendy.Buffer.new(w, h)
+        bendy.unshard(torch.cat(shards), out, world)
+        torch.cuda.synchronize()
+        st = sc.last_stats()
+        assert np.array_equal(out.numpy(), it)
+    blocks = -(-tiles // world) * st.slices
+    assert st.packed == (1 if blocks > _workgroup_slots() else 0)
+    if st.packed:
+        assert st.workgroups == _workgroup_slots() and (not slices or st.slices == slices)
+
+
+def test_packing_is_automatic_for_mid_sized_launches_and_absent_elsewhere(bendy, oracle):
+    """bt_api.cpp packs launches of ~1 ... 24 work items per lane of the GPU (the interactive pattern on a 768 x 512 frame:
+    4 rays per pixel, 3.4 items per lane on an MI355X) -- Full output without the lens only: the AOV and lens builds have no packed variant."""
+    import torch
+    w, h = 768, 512
+    it, seg = oracle_render(oracle, "scene", w, h, 1, n=2, threads=16)
+    for packed, expect in ((-1, 1), (0, 0), (1, 1)):
+        sc, cam = gpu_scene(bendy, "scene", w, h, tuning={"packed": packed})
+        buf = bendy.Buffer.new(w, h)
+        tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+        tr.render(sc, cam, bendy.RenderConfig.with_samples_subsample(1, bendy.Subsample(2)), buf)
+        torch.cuda.synchronize()
+        st = sc.last_stats()
+        assert st.packed == expect and st.segments == seg and np.array_equal(buf.numpy(), it)
+    # a deep launch is never packed on its own
+    _, st, _ = gpu_render(bendy, "scene", 320, 200, 300)
+    assert st.packed == 0
+    # AOV outputs and the lens extension: asked for, not available -> one block per workgroup, same bits
+    buf, st, _ = gpu_render(bendy, "scene", 400, 260, 2, output=2, tuning={"packed": 1})
+    it2, _ = oracle_render(oracle, "scene", 400, 260, 2, output=2, threads=16)
+    assert st.packed == 0 and np.array_equal(buf.numpy(), it2)
+
+
 @pytest.mark.parametrize("max_wait", [0, 1, 2, 7])
 @pytest.mark.parametrize("name,w,h,spp", [("scene", 96, 54, 24), ("cloud", 64, 48, 12)])
 def test_phase_vote_is_scheduling_only(bendy, oracle, name, w, h, spp, max_wait):

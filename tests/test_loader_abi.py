@@ -234,14 +234,14 @@ def test_tuning_is_per_handle_and_validated(bendy, monkeypatch):
     process global; out-of-set values are rejected; NULL restores the defaults."""
     a = bendy.Scene.load(scene_path("scene"))
     b = bendy.Scene.load(scene_path("scene"))
-    default = dict(slices=0, phase_vote=-1, scratch_cap_bytes=0)
+    default = dict(slices=0, phase_vote=-1, scratch_cap_bytes=0, packed=-1, reserved=0)
     assert a.tuning() == default
-    a.set_tuning(slices=8, phase_vote=5, scratch_cap_bytes=1 << 20)
-    assert a.tuning() == {**default, "slices": 8, "phase_vote": 5, "scratch_cap_bytes": 1 << 20}
+    a.set_tuning(slices=8, phase_vote=5, scratch_cap_bytes=1 << 20, packed=1)
+    assert a.tuning() == {**default, "slices": 8, "phase_vote": 5, "scratch_cap_bytes": 1 << 20, "packed": 1}
     assert b.tuning() == default                     # another handle is untouched
     a.set_tuning(phase_vote=0)                       # fields not named keep their value
     assert a.tuning()["slices"] == 8 and a.tuning()["phase_vote"] == 0
-    for bad in (dict(slices=3), dict(slices=64), dict(phase_vote=-2), dict(phase_vote=65)):
+    for bad in (dict(slices=3), dict(slices=64), dict(phase_vote=-2), dict(phase_vote=65), dict(packed=2), dict(packed=-2)):
         with pytest.raises(bendy.BendyError) as e:
             a.set_tuning(**bad)
         assert e.value.code == -1

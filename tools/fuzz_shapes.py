@@ -32,7 +32,11 @@ for case in range(n):
     sub = rng.choice([0, 0, 2, 3]) if spp <= 8 else 0
     world = rng.choice([1, 1, 1, 2, 3])
     pin = rng.choice([None, None, None, 1, 2, 4, 8, 16, 32])      # bt_tuning.slices: every block shape, not only the automatic one
-    sc, cam = gpu_scene(bendy, name, w, h, tuning={"slices": pin} if pin else None)
+    packed = rng.choice([-1, 0, 1, 1])                            # bt_tuning.packed: several blocks behind one queue
+    tuning = {"packed": packed}
+    if pin:
+        tuning["slices"] = pin
+    sc, cam = gpu_scene(bendy, name, w, h, tuning=tuning)
     tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
     rc = bendy.RenderConfig.with_samples_subsample(spp, bendy.Subsample(sub)) if sub else bendy.RenderConfig.with_samples(spp)
     if world == 1:
@@ -53,13 +57,13 @@ for case in range(n):
     st = sc.last_stats()
     it, seg = oracle_render(oracle, name, w, h, spp, n=sub, recursive=0, threads=16)
     ok = np.array_equal(got[..., :3], it[..., :3], equal_nan=True)
-    key = (st.slices, st.launches)
+    key = (st.slices, st.launches, packed)
     seen[key] = seen.get(key, 0) + 1
     if not ok:
         bad += 1
         print(f"MISMATCH case {case}: {name} {w}x{h} spp {spp} sub {sub} world {world} slices {st.slices}", flush=True)
     if case % 50 == 49:
         print(f"... {case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
-print("slices / launches seen:", dict(sorted(seen.items())))
+print("slices / launches / packed seen:", dict(sorted(seen.items())))
 print(f"launch shapes: {n - bad} of {n} cases bit-identical to the oracle")
 sys.exit(1 if bad else 0)
