@@ -57,13 +57,13 @@ for case in range(n):
     st = sc.last_stats()
     it, seg = oracle_render(oracle, name, w, h, spp, n=sub, recursive=0, threads=16)
     ok = np.array_equal(got[..., :3], it[..., :3], equal_nan=True)
-    key = (st.slices, st.launches, packed)
+    key = (st.slices, st.launches, packed, st.packed)
     seen[key] = seen.get(key, 0) + 1
     if not ok:
         bad += 1
         print(f"MISMATCH case {case}: {name} {w}x{h} spp {spp} sub {sub} world {world} slices {st.slices}", flush=True)
     if case % 50 == 49:
         print(f"... {case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
-print("slices / launches / packed seen:", dict(sorted(seen.items())))
+print("slices / launches / packed knob / packed launch seen:", dict(sorted(seen.items())))
 print(f"launch shapes: {n - bad} of {n} cases bit-identical to the oracle")
 sys.exit(1 if bad else 0)
