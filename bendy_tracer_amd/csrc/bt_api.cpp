@@ -26,6 +26,9 @@ extern "C" hipError_t bt_launch_preview(const float *rgba, uint8_t *out, uint32_
 
 static_assert(BT_TILE == BT_TILE_DIM, "public and device tile sizes must agree");
 
+#ifndef BT_POOL_RECORDS
+#define BT_POOL_RECORDS 128        // PathRec records per workgroup for the drain of a packed rect launch (at most 256)
+#endif
 namespace {
 
 thread_local std::string g_error;
@@ -477,19 +480,27 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
         if (pxb * chunk * nn > items_max) chunk = (uint32_t)std::max<uint64_t>(1, items_max / (pxb * nn));
     }
     // Packed launch: when the whole render is one launch of at most a few generations of workgroups, ONE generation -- a workgroup
-    // per workgroup slot of the GPU, each owning every n_workgroups-th block of 8 pixels behind one queue -- ends with one drain
+    // per workgroup slot of the GPU, each owning every n_workgroups-th small pixel block behind one queue -- ends with one drain
     // of its longest paths instead of one per generation.
     P.wg_blocks = 1;
     P.wg_blocks_rem = 0;
     P.n_workgroups = 0;
     P.log_rows = 0;
     P.row_mask = 0xffffffffu;
+    P.pool_records = 0;
+    P.pool_lds_offset = 0;
+    // The drain of a packed launch compacts the paths in flight through LDS records (bt_kernels.hip PathRec, 80 B): room for 128
+    // behind the tables, where that does not cost a workgroup slot and the packed record fields are wide enough.
+    const size_t pool_offset = (lds_bytes + 15) & ~(size_t)15, pool_bytes = BT_POOL_RECORDS * 80;
+    bool pool_ok = tune.packed != 1 && P.any_rects && !P.any_volumes &&            // (the rect build is the one that has the code)
+                   P.max_bounces < 0xfff0 && P.max_volume_bounces < 0xfff0 && s->flat.prims.size() < 0xfffff0u;
     // workgroup slots of the GPU: 7 per CU by the builds' __launch_bounds__ (72 VGPRs), fewer when the scene tables are large
     // (160 KB of LDS per CU, allocated in 2 KB steps here to stay on the safe side)
-    const uint32_t wg_lds = (uint32_t)((lds_bytes + 64 + 2047) & ~(size_t)2047);
-    const uint32_t wg_slots = (uint32_t)s->n_cu * std::max(1u, std::min(7u, 160u * 1024u / wg_lds));
+    auto slots_per_cu = [](size_t lds) { return std::max(1u, std::min(7u, 160u * 1024u / (uint32_t)((lds + 64 + 2047) & ~(size_t)2047))); };
+    pool_ok = pool_ok && slots_per_cu(pool_offset + pool_bytes) == slots_per_cu(lds_bytes);
+    const uint32_t wg_slots = (uint32_t)s->n_cu * slots_per_cu(lds_bytes);
     const uint64_t T_launch = (uint64_t)chunk * nn;
-    // Measured (profiles/r04s: 512 x 512 ... 1920 x 1080 frames, 1 ... 32 rays per pixel, three scene classes): packing pays
+    // Measured (profiles/r04t: 256 x 256 ... 1920 x 1080 frames, 1 ... 64 rays per pixel, three scene classes): packing pays
     // between ~1 and ~24 work items per lane of the GPU (scene.json 768 x 512 x 4: 0.121 -> 0.09 ms); deeper launches overlap
     // their drains with other workgroups' work and lose 5 - 20 % when packed, emptier ones do not fill the slots
     const uint64_t items_all = px_launch * T_launch, lanes_all = (uint64_t)wg_slots * 256;
@@ -512,6 +523,11 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
             P.wg_blocks_rem = (uint32_t)(blocks - (per_wg - 1) * wg_slots);
             P.log_rows = log_rows;
             P.row_mask = (1u << log_rows) - 1u;
+            if (pool_ok) {
+                P.pool_records = BT_POOL_RECORDS;
+                P.pool_lds_offset = (uint32_t)pool_offset;
+                lds_bytes = pool_offset + pool_bytes;
+            }
         } else if (!s->d_scratch && !ensure_scratch(per_sample * chunk)) {
             return set_error(BT_ERR_DEVICE, "no device memory for the parked samples");
         }
@@ -560,7 +576,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     s->last.kernel_ms = 0.0f;
     s->last.slices = (uint32_t)P.slices;
     s->last.launches = launches;
-    s->last.packed = P.wg_blocks > 1 ? 1u : 0u;
+    s->last.packed = P.wg_blocks > 1 ? (P.pool_records ? 2u : 1u) : 0u;
     s->last.workgroups = P.wg_blocks > 1 ? P.n_workgroups : grid * (uint32_t)P.slices;
     s->last.scratch_bytes = s->scratch_bytes;
     s->last.parked_bytes = parked_bytes;
@@ -612,7 +628,7 @@ int bt_scene_set_tuning(bt_scene *scene, const bt_tuning *t) {
         return set_error(BT_ERR_INVALID_ARG, "bt_tuning.slices must be 0 (auto), 1, 2, 4, 8, 16 or 32");
     if (t->phase_vote < -1 || t->phase_vote > 64)
         return set_error(BT_ERR_INVALID_ARG, "bt_tuning.phase_vote must be -1 .. 64");
-    if (t->packed < -1 || t->packed > 1) return set_error(BT_ERR_INVALID_ARG, "bt_tuning.packed must be -1, 0 or 1");
+    if (t->packed < -1 || t->packed > 2) return set_error(BT_ERR_INVALID_ARG, "bt_tuning.packed must be -1, 0, 1 or 2");
     scene->tuning = *t;
     return 0;
 }

@@ -38,6 +38,9 @@
 // r04e, r04f).
 #include "bt_device.hpp"
 
+#ifndef BT_DRAIN_SHIFT
+#define BT_DRAIN_SHIFT 1           // packed rect build: a drain round every 2^BT_DRAIN_SHIFT iterations
+#endif
 #define BT_SUM_BATCH 8             // parked values a lane of the summing wave has in flight (16: no difference, profiles/r04k)
 
 // Developer build (-DBT_PROFILE): s_memtime stamps around the sections of the render loop, summed per wave into
@@ -64,6 +67,10 @@ namespace {
 struct Parked { float x, y, z; };
 
 enum { EV_GEN = 0, EV_DIFFUSE = 1, EV_METALLIC = 2, EV_GLASS = 3, EV_VOLUME = 4 };
+
+// A path in flight, as it changes lanes in the drain of a packed launch (80 bytes): ray, throughput, radiance; event counter,
+// pixel, work item; bounce | volume bounce << 16; in-volume object + 1 | vote wait << 24 | held << 31; the held hit.
+struct __attribute__((aligned(16))) PathRec { float f[12]; uint32_t w[8]; };
 
 // lanes of a wave64 mask below this lane
 BT_DEV uint32_t lanes_below(unsigned long long m) {
@@ -253,10 +260,12 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     __shared__ uint32_t s_waves_done;      // block queue: waves of this workgroup that have parked all their samples
     __shared__ uint32_t s_next_item;       // the workgroup's work queue (next unclaimed (pixel, sample) pair)
     __shared__ uint32_t s_segments;        // path segments traced by this workgroup
+    __shared__ uint32_t s_pool_paths[2], s_pool_waves[2];   // packed builds, drain rounds: live paths / waves that hold any (two sets, alternating)
     if (threadIdx.x == 0) {
         s_waves_done = 0;
         s_next_item = 0;
         s_segments = 0;
+        if (PACKED && RECTS && !VOLS) s_pool_paths[0] = s_pool_paths[1] = s_pool_waves[0] = s_pool_waves[1] = 0;
     }
 
     // ---- stage the per-lane lookup tables in LDS ----
@@ -378,12 +387,27 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         park()[park_i] = Parked{value.x, value.y, value.z};
     };
 
+    // Packed builds, the drain (BtLaunch::pool_records > 0): once the queue is empty the workgroup's waves meet at the end of every
+    // second iteration, put the paths still in flight into LDS records and take them back densely packed -- waves 1 .. 3 run out of
+    // paths and stop issuing instructions for a handful of live lanes each.  Scheduling only: a path's state moves between lanes,
+    // its operations and their order do not change.  Every wave takes part in every round (barriers pair up by count) until
+    // a round finds no path left.
+    PathRec *const pool = (PathRec *)(smem + P.pool_lds_offset);
+    // Compiled into the rect build only: measured (profiles/r04y), it takes 4 - 14 % off packed Cornell-box launches and nothing off
+    // sphere and volume launches (short drains; marches), whose builds its code made ~5 % slower.
+    constexpr bool CAN_COMPACT = PACKED && RECTS && !VOLS;
+    const bool compacting = CAN_COMPACT && P.pool_records > 0;
+    bool dry_lane = false;             // this lane found the queue empty
+    uint32_t drain_it = 0;             // iterations since the wave saw the queue empty (wave-uniform)
+
     BT_PROF_DECL;
 #ifdef BT_LANESTAT
     unsigned long long ls_acc[9] = {};
     const unsigned long long ls_all = __ballot(true);
 #endif
     for (;;) {
+        do {                                              // (`continue` below = on to the latch at the end of the iteration)
+        if (compacting && dry_lane && pending) continue;  // the queue is empty and this lane has no path: nothing to do
         BT_LS(0, 1ull);
         BT_LS(8, ls_all & ~__ballot(true));
         BT_PROF(0);                                       // loop overhead / previous iteration's tail
@@ -502,6 +526,10 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             }
         }
         pending = false;
+        if (compacting && dry_lane && ev == EV_GEN) {     // the queue is empty: a lane whose path has just ended is done (and has no vote)
+            pending = true;
+            continue;
+        }
 
         if (VOTE && P.phase_vote) {
             // ---- which events run this iteration?  The kind more lanes want (camera | scatter / volume step); nobody waits
@@ -538,7 +566,12 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
                 if (ev == EV_GEN) {
                     const uint32_t i = base + lanes_below(need);
-                    if (i >= n_items) break;                              // the block's samples are all taken
+                    if (i >= n_items) {                                   // the block's samples are all taken
+                        if (!compacting) goto queue_empty;                // this lane is done
+                        dry_lane = true;                                  // the wave learns of it at the end of the iteration
+                        pending = true;
+                        continue;
+                    }
                     park_i = i;                                           // (+ the workgroup's base, see finish_sample)
                     BlockRef B_i = B_own;
                     bool hole = false;
@@ -768,7 +801,56 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
             pending = true;
         }
         BT_PROF(5);                                       // normalize, pdf weight (light_pdf), bookkeeping
+        } while (0);
+        // ---- the latch: every lane of the wave passes here once per iteration, together -- the drain rounds of the packed builds
+        // contain barriers, so they must not sit where lanes that skip the body could run ahead of the others (at the top of the
+        // loop the compiler split `round; if (no path) continue;` off as an inner loop of its own: a wave's idle lanes then met
+        // the barrier alone, again and again)
+        if (compacting && __ballot(dry_lane) != 0ull) {                   // wave-uniform: the queue is empty
+            dry_lane = true;
+            if ((drain_it & ((1u << BT_DRAIN_SHIFT) - 1u)) == 0u) {
+                const uint32_t set = (drain_it >> BT_DRAIN_SHIFT) & 1u;
+                const bool alive = !pending;                              // a path in flight (possibly holding its hit for the vote)
+                const unsigned long long m = __ballot(alive);
+                uint32_t base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(&s_pool_paths[set], popc64(m));
+                    if (m) atomicAdd(&s_pool_waves[set], 1u);
+                }
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t slot = base + lanes_below(m);
+                if (alive && slot < P.pool_records) {
+                    PathRec r;
+                    r.f[0] = ro.x; r.f[1] = ro.y; r.f[2] = ro.z; r.f[3] = rd.x; r.f[4] = rd.y; r.f[5] = rd.z;
+                    r.f[6] = beta.x; r.f[7] = beta.y; r.f[8] = beta.z; r.f[9] = L.x; r.f[10] = L.y; r.f[11] = L.z;
+                    r.w[0] = event; r.w[1] = pixel_index; r.w[2] = park_i;
+                    r.w[3] = (uint32_t)bounce | ((uint32_t)vbounce << 16);
+                    r.w[4] = ((uint32_t)(last_object + 1) & 0xffffffu) | ((uint32_t)waited << 24) | (held ? 0x80000000u : 0u);
+                    r.w[5] = __float_as_uint(held_t); r.w[6] = (uint32_t)held_info; r.w[7] = 0u;
+                    pool[slot] = r;
+                }
+                __syncthreads();
+                const uint32_t total = *(volatile uint32_t *)&s_pool_paths[set], holders = *(volatile uint32_t *)&s_pool_waves[set];
+                if (threadIdx.x == 0) { s_pool_paths[set ^ 1u] = 0; s_pool_waves[set ^ 1u] = 0; }   // next round's set: last read a round ago
+                if (total == 0u) break;                                   // no path left in the workgroup: every wave leaves here
+                if (total <= P.pool_records && holders > (total + 63u) / 64u) {   // the paths fit fewer waves than hold them now
+                    pending = threadIdx.x >= total;
+                    if (!pending) {
+                        const PathRec r = pool[threadIdx.x];
+                        ro = mk(r.f[0], r.f[1], r.f[2]); rd = mk(r.f[3], r.f[4], r.f[5]);
+                        beta = mk(r.f[6], r.f[7], r.f[8]); L = mk(r.f[9], r.f[10], r.f[11]);
+                        event = r.w[0]; pixel_index = r.w[1]; park_i = r.w[2];
+                        bounce = (int)(r.w[3] & 0xffffu); vbounce = (int)(r.w[3] >> 16);
+                        last_object = (int)(r.w[4] & 0xffffffu) - 1; waited = (int)((r.w[4] >> 24) & 0x7fu); held = (r.w[4] >> 31) != 0u;
+                        held_t = __uint_as_float(r.w[5]); held_info = (int)r.w[6];
+                    }
+                }
+                __syncthreads();                                          // records are read before the next round overwrites them
+            }
+            drain_it += 1u;
+        }
     }
+queue_empty:;
 
     // ---- the end of a workgroup --------------------------------------------------------------------------------------
     // Block queue: the last wave of the workgroup to get here performs `*r += pixel.r` (buffer.rs:159-164) for every parked

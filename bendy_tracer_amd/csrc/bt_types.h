@@ -225,6 +225,8 @@ struct BtLaunch {
     // share the launch's blocks, workgroup w owning blocks w, w + n_workgroups, ... (wg_blocks of them, one less from workgroup
     // wg_blocks_rem on) behind one queue.  wg_blocks = 1: one block per workgroup.
     uint32_t wg_blocks, wg_blocks_rem, n_workgroups;
+    uint32_t pool_records, pool_lds_offset;   // packed: PathRec records behind the tables in dynamic LDS for the drain's compaction
+                                      // rounds (bt_kernels.hip), 0 = none: lanes leave the loop when the queue is empty
     uint32_t log_rows, row_mask;      // packed: a block's T = samples * n^2 samples are padded to 2^log_rows rows in the queue and in
                                       // scratch, row_mask = 2^log_rows - 1; not packed: row_mask = 0xffffffff
 };

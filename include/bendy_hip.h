@@ -87,8 +87,8 @@ typedef struct {
     uint64_t scratch_bytes;    /* HBM the handle holds for parked sample values after this render */
     uint64_t parked_bytes;     /* bytes of sample values the render parked in HBM (12 per sample, edge tiles padded) */
     uint32_t workgroups;       /* workgroups of the last launch */
-    uint32_t packed;           /* 1: the last launch was packed (bt_tuning.packed): `workgroups` = the GPU's workgroup slots, each
-                                * owning every workgroups-th pixel block behind one queue */
+    uint32_t packed;           /* 1 / 2: the last launch was packed (bt_tuning.packed; 2 = with the compacting drain): `workgroups` = the
+                                * GPU's workgroup slots, each owning every workgroups-th pixel block behind one queue */
 } bt_stats;
 
 /* Launch-shape knobs of a scene handle.  Every field's zero / negative value means "let the library decide" (what
@@ -99,8 +99,9 @@ typedef struct {
     int32_t phase_vote;        /* -1 = auto; 0 = off; n = longest wait of the phase vote in iterations */
     uint64_t scratch_cap_bytes;/* 0 = the default 2 GiB: most parked sample values per launch; deeper renders are split into
                                 * several launches over consecutive sample ranges */
-    int32_t packed;            /* -1 = auto; 0 = one pixel block per workgroup; 1 = packed launch where one fits: one workgroup per
-                                * workgroup slot of the GPU, each owning every n-th pixel block behind one queue */
+    int32_t packed;            /* -1 = auto; 0 = one pixel block per workgroup; 1 / 2 = packed launch where one fits: one workgroup per
+                                * workgroup slot of the GPU, each owning every n-th pixel block behind one queue --
+                                * 2 (what auto uses): its drain compacts the paths in flight into fewer waves through LDS records */
     int32_t reserved;
 } bt_tuning;
 

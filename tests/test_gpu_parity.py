@@ -303,13 +303,15 @@ def _workgroup_slots():
     ("cloud", 512, 300, 1, 0, 4),        # one ray per pixel, whole quadrants
     ("cornell", 330, 200, 2, 3, 8),      # 18 -> 32 rows, ragged right / bottom tiles
 ])
-def test_packed_launches(bendy, oracle, name, w, h, samples, n, slices, world):
+@pytest.mark.parametrize("packed", [1, 2])
+def test_packed_launches(bendy, oracle, name, w, h, samples, n, slices, world, packed):
     """bt_tuning.packed = 1: one workgroup per workgroup slot of the GPU, each owning every k-th pixel block behind ONE queue
-    (rows of a block padded to a power of two), all its waves summing the parked values at the end -- scheduling only, the
-    oracle's bits in the full-frame and in the sharded layout."""
+    (rows of a block padded to a power of two), all its waves summing the parked values at the end; packed = 2: the drain moves
+    the paths in flight between lanes through LDS records -- scheduling only, the oracle's bits in the full-frame and in the
+    sharded layout."""
     import torch
     it, seg = oracle_render(oracle, name, w, h, samples, n=n, threads=16)
-    tuning = {"packed": 1}
+    tuning = {"packed": packed}
     if slices:
         tuning["slices"] = slices
     sc, cam = gpu_scene(bendy, name, w, h, tuning=tuning)
@@ -334,7 +336,8 @@ def test_packed_launches(bendy, oracle, name, w, h, samples, n, slices, world):
         st = sc.last_stats()
         assert np.array_equal(out.numpy(), it)
     blocks = -(-tiles // world) * st.slices
-    assert st.packed == (1 if blocks > _workgroup_slots() else 0)
+    has_drain_rounds = name in ("cornell", "cornell2")          # the compacting drain is compiled into the rect build only
+    assert st.packed == ((packed if has_drain_rounds else 1) if blocks > _workgroup_slots() else 0)
     if st.packed:
         assert st.workgroups == _workgroup_slots() and (not slices or st.slices == slices)
 
@@ -345,7 +348,7 @@ def test_packing_is_automatic_for_mid_sized_launches_and_absent_elsewhere(bendy,
     import torch
     w, h = 768, 512
     it, seg = oracle_render(oracle, "scene", w, h, 1, n=2, threads=16)
-    for packed, expect in ((-1, 1), (0, 0), (1, 1)):
+    for packed, expect in ((-1, 1), (0, 0), (1, 1), (2, 1)):         # sphere builds have no drain rounds: 2 falls back to 1
         sc, cam = gpu_scene(bendy, "scene", w, h, tuning={"packed": packed})
         buf = bendy.Buffer.new(w, h)
         tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
@@ -353,6 +356,10 @@ def test_packing_is_automatic_for_mid_sized_launches_and_absent_elsewhere(bendy,
         torch.cuda.synchronize()
         st = sc.last_stats()
         assert st.packed == expect and st.segments == seg and np.array_equal(buf.numpy(), it)
+    # BASELINE configs[1] (C2) is such a launch on the rect build: packed, with the compacting drain
+    buf, st, _ = gpu_render(bendy, "cornell2", 512, 512, 16)
+    it2, seg2 = oracle_render(oracle, "cornell2", 512, 512, 16, threads=16)
+    assert st.packed == 2 and st.segments == seg2 and np.array_equal(buf.numpy(), it2)
     # a deep launch is never packed on its own
     _, st, _ = gpu_render(bendy, "scene", 320, 200, 300)
     assert st.packed == 0

@@ -241,7 +241,7 @@ def test_tuning_is_per_handle_and_validated(bendy, monkeypatch):
     assert b.tuning() == default                     # another handle is untouched
     a.set_tuning(phase_vote=0)                       # fields not named keep their value
     assert a.tuning()["slices"] == 8 and a.tuning()["phase_vote"] == 0
-    for bad in (dict(slices=3), dict(slices=64), dict(phase_vote=-2), dict(phase_vote=65), dict(packed=2), dict(packed=-2)):
+    for bad in (dict(slices=3), dict(slices=64), dict(phase_vote=-2), dict(phase_vote=65), dict(packed=3), dict(packed=-2)):
         with pytest.raises(bendy.BendyError) as e:
             a.set_tuning(**bad)
         assert e.value.code == -1

@@ -32,7 +32,7 @@ for case in range(n):
     sub = rng.choice([0, 0, 2, 3]) if spp <= 8 else 0
     world = rng.choice([1, 1, 1, 2, 3])
     pin = rng.choice([None, None, None, 1, 2, 4, 8, 16, 32])      # bt_tuning.slices: every block shape, not only the automatic one
-    packed = rng.choice([-1, 0, 1, 1])                            # bt_tuning.packed: several blocks behind one queue
+    packed = rng.choice([-1, 0, 1, 2, 2])                            # bt_tuning.packed: several blocks behind one queue
     tuning = {"packed": packed}
     if pin:
         tuning["slices"] = pin

@@ -10,7 +10,7 @@ names = os.environ.get('BT_ONLY', 'scene,cornell2,volume').split(',')
 shapes = [(1, 1), (2, 1), (1, 2), (8, 1), (16, 1), (32, 1), (64, 1)]
 if os.environ.get('BT_T'):
     shapes = [(int(t), 1) if t != '4' else (1, 2) for t in os.environ['BT_T'].split(',')]
-modes = os.environ.get('BT_MODES', 'auto,s1,s2,s4,s8,p32').split(',')     # u = one block per workgroup; sN = the same with blocks of 256/N pixels; p / pN = packed launch (with such blocks)
+modes = os.environ.get('BT_MODES', 'auto,s1,s2,s4,s8,p32').split(',')     # u = one block per workgroup; sN = the same with blocks of 256/N pixels; p / pN = packed launch (with such blocks); c / cN = packed with the compacting drain
 for name in names:
     sc = b.Scene.load(f'scenes/{name}.json.gz'); cam = sc.find_by_tag('camera'); sc.set_camera_aspect(cam, w / h)
     tr = b.Tracer.with_config(b.Config(chunks_x=8, chunks_y=4))
@@ -24,6 +24,8 @@ for name in names:
                 sc.set_tuning(slices=int(mode[1:]), packed=0)
             elif mode[0] == 'p':
                 sc.set_tuning(packed=1, slices=int(mode[1:] or 0))
+            elif mode[0] == 'c':
+                sc.set_tuning(packed=2, slices=int(mode[1:] or 0))
             buf = b.Buffer.new(w, h)
             rc = b.RenderConfig.with_samples_subsample(samples, b.Subsample(sub))
             try:
