@@ -133,6 +133,27 @@ def test_progressive_calls_accumulate_like_the_reference(bendy, oracle):
     assert buf.samples == 0 and float(buf.numpy()[..., :3].sum()) == 0.0 and (buf.numpy()[..., 3] == 1).all()
 
 
+@pytest.mark.parametrize("name", ["scene", "cornell2"])
+def test_progressive_packed_calls_equal_one_deep_call(bendy, oracle, name):
+    """The interactive loop on a frame large enough for packed launches: four calls of 1 sample x Subpixel(2), each
+    a packed launch adding into the running sums, equal one call of 4 samples (a different launch shape) and the oracle; a scratch
+    cap that splits the render into several launches keeps it unpacked, same bits."""
+    w, h = 512, 320                                  # 640 tiles x 256 pixels x 4 rays: 1.4 work items per lane of an MI355X
+    it, seg = oracle_render(oracle, name, w, h, 4, n=2, threads=16)
+    sc, cam = gpu_scene(bendy, name, w, h)
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    buf = bendy.Buffer.new(w, h)
+    segments = 0
+    for i in range(4):
+        tr.render(sc, cam, bendy.RenderConfig.with_samples_subsample(1, bendy.Subsample(2)), buf)
+        st = sc.last_stats()
+        assert st.packed >= 1
+        segments += st.segments
+    assert buf.samples == 16 and segments == seg and np.array_equal(buf.numpy(), it)
+    capped, st, _ = gpu_render(bendy, name, w, h, 4, n=2, tuning={"packed": 2, "scratch_cap_bytes": 32 * 20 * 256 * 12 * 8})
+    assert st.launches == 2 and st.packed == 0 and np.array_equal(capped.numpy(), it)
+
+
 def test_prefilled_buffer_is_added_to_not_overwritten(bendy, oracle):
     import torch
     w, h = 48, 27
