@@ -24,6 +24,8 @@ for name in names:
                 sc.set_tuning(slices=int(mode[1:]), packed=0)
             elif mode[0] == 'p':
                 sc.set_tuning(packed=1, slices=int(mode[1:] or 0))
+            elif mode[0] == 'v':                          # automatic shape, phase vote pinned to N iterations
+                sc.set_tuning(phase_vote=int(mode[1:]))
             elif mode[0] == 'c':
                 sc.set_tuning(packed=2, slices=int(mode[1:] or 0))
             buf = b.Buffer.new(w, h)
