@@ -174,6 +174,7 @@ int ensure_device(bt_scene *s) {
                 BtSpherePair q{};
                 q.cx[0] = A.c.x; q.cy[0] = A.c.y; q.cz[0] = A.c.z; q.radius[0] = A.radius; q.object[0] = A.object;
                 q.cx[1] = B.c.x; q.cy[1] = B.c.y; q.cz[1] = B.c.z; q.radius[1] = B.radius; q.object[1] = B.object;
+                q.r2[0] = A.radius * A.radius; q.r2[1] = B.radius * B.radius;
                 pairs.push_back(q);
             }
         BT_HIP(s->d_sphere_pairs.upload(pairs));

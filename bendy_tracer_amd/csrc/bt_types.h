@@ -59,7 +59,7 @@ static_assert(sizeof(BtPrim) == 144, "BtPrim must be 144 bytes");
 struct BtSpherePair {
     float cx[2], cy[2], cz[2], radius[2];
     int32_t object[2];
-    int32_t pad[2];
+    float r2[2];            // radius * radius (sphere.rs:130), multiplied once on the host: the same IEEE product
 };
 static_assert(sizeof(BtSpherePair) == 48, "BtSpherePair must be 48 bytes");
 
