@@ -77,6 +77,7 @@ struct bt_scene {
     DeviceArray<BtLight> d_lights;
     DeviceArray<BtLightFace> d_light_faces;
     DeviceArray<BtSpherePair> d_sphere_pairs;
+    DeviceArray<BtSphereRow> d_sphere_rows;
     DeviceArray<BtRectAAN> d_aan_rows;
     DeviceArray<BtRectLA> d_la_rows;
     DeviceArray<int32_t> d_other_rows;
@@ -174,10 +175,14 @@ int ensure_device(bt_scene *s) {
                 BtSpherePair q{};
                 q.cx[0] = A.c.x; q.cy[0] = A.c.y; q.cz[0] = A.c.z; q.radius[0] = A.radius; q.object[0] = A.object;
                 q.cx[1] = B.c.x; q.cy[1] = B.c.y; q.cz[1] = B.c.z; q.radius[1] = B.radius; q.object[1] = B.object;
-                q.r2[0] = A.radius * A.radius; q.r2[1] = B.radius * B.radius;
                 pairs.push_back(q);
             }
         BT_HIP(s->d_sphere_pairs.upload(pairs));
+        std::vector<BtSphereRow> rows;
+        if (spheres_only)
+            for (const BtPrim &R : pr) rows.push_back(BtSphereRow{R.c.x, R.c.y, R.c.z, R.radius * R.radius});
+        if (rows.size() & 1) rows.push_back(rows.back());           // (never visited: keeps an x8 load of the last pair inside the table)
+        BT_HIP(s->d_sphere_rows.upload(rows));
     }
     BT_HIP(s->d_density.upload(s->flat.density));
     BT_HIP(s->d_aan_rows.upload(s->flat.aan_rows));
@@ -264,6 +269,7 @@ int fill_launch(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const bt
     P.lights = s->d_lights.ptr;
     P.light_faces = s->d_light_faces.ptr;
     P.sphere_pairs = s->d_sphere_pairs.count ? s->d_sphere_pairs.ptr : nullptr;
+    P.sphere_rows = s->d_sphere_rows.count ? s->d_sphere_rows.ptr : nullptr;
     P.density = s->d_density.ptr;
     P.n_prims = (int32_t)f.prims.size();
     P.n_materials = (int32_t)f.materials.size();

@@ -422,8 +422,8 @@ BT_DEV HitRec intersect_sphere_pairs(const BtLaunch &P, V3 o, V3 d, float tmin, 
 }
 
 // The scan for scenes without volumes (scene.json): an odd table's last sphere is visited on its own (no arithmetic for an empty
-// second slot: 18 instructions per path segment with scene.json's five spheres) and radius^2 comes from the table
-// (C3 3.02 -> 2.90 ms on one box, profiles/r05e).
+// second slot: 18 instructions per path segment with scene.json's five spheres), radius^2 comes from the table and a sphere is
+// one 16-byte row (BtSphereRow: one scalar load per pair instead of three) -- C3 3.03 -> 2.92 ms on one box, profiles/r05f.
 BT_DEV HitRec intersect_spheres_plain(const BtLaunch &P, V3 o, V3 d, float tmin, float tmax) {
     HitRec h;
     h.t = tmax;
@@ -431,29 +431,27 @@ BT_DEV HitRec intersect_spheres_plain(const BtLaunch &P, V3 o, V3 d, float tmin,
     h.inside = false;
     h.p_neg = false;
     const int n = P.n_prims;
-    typedef const __attribute__((address_space(4))) BtSpherePair PairK;
-    PairK *pairs = (PairK *)P.sphere_pairs;
+    typedef const __attribute__((address_space(4))) BtSphereRow RowK;
+    RowK *rows = (RowK *)P.sphere_rows;         // wave-uniform indices -> scalar loads: x8 for two spheres, x4 for one
     // one sphere's turn in try_hit's scan, from its discriminant on (sphere_t()'s root selection; sphere.rs:121-148)
     auto visit = [&](int row, float ds, float hb) {
         if (ds >= 0.0f) {
             const float sqrtd = sqrt_bt(ds);
-            float t = -hb - sqrtd;
-            bool ok = !(t < tmin || t > h.t);
-            if (!ok) {
-                t = -hb + sqrtd;
-                ok = !(t < tmin || t > h.t);
-            }
-            if (ok) {
-                h.t = t;
-                h.prim = row;
-            }
+            // both roots and their range tests, then selects: the branches of sphere_t()'s "first root, else second" cost the
+            // scalar unit more than the three extra instructions cost the vector unit (C3 2.766 -> 2.744 ms, profiles/r05j)
+            const float t1 = -hb - sqrtd, t2 = -hb + sqrtd;
+            const bool ok1 = !(t1 < tmin || t1 > h.t), ok2 = !(t2 < tmin || t2 > h.t);
+            const float t = ok1 ? t1 : t2;
+            const bool ok = ok1 | ok2;
+            h.t = ok ? t : h.t;
+            h.prim = ok ? row : h.prim;
         }
     };
     const int n_paired = n & ~1;
     int i = 0;
     for (; i < n_paired; i += 2) {
-        PairK &Q = pairs[i >> 1];               // wave-uniform index -> scalar loads
-        const f2 cx = {Q.cx[0], Q.cx[1]}, cy = {Q.cy[0], Q.cy[1]}, cz = {Q.cz[0], Q.cz[1]}, r2 = {Q.r2[0], Q.r2[1]};
+        RowK &A = rows[i], &B = rows[i + 1];
+        const f2 cx = {A.cx, B.cx}, cy = {A.cy, B.cy}, cz = {A.cz, B.cz}, r2 = {A.r2, B.r2};
         const f2 ocx = splat2(o.x) - cx, ocy = splat2(o.y) - cy, ocz = splat2(o.z) - cz;
         const f2 half_b = (ocx * d.x + ocy * d.y) + ocz * d.z;
         const f2 cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;
@@ -462,10 +460,10 @@ BT_DEV HitRec intersect_spheres_plain(const BtLaunch &P, V3 o, V3 d, float tmin,
         visit(i + 1, disc.y, half_b.y);
     }
     if (i < n) {
-        PairK &Q = pairs[i >> 1];
-        const float ocx = o.x - Q.cx[0], ocy = o.y - Q.cy[0], ocz = o.z - Q.cz[0];
+        RowK &A = rows[i];
+        const float ocx = o.x - A.cx, ocy = o.y - A.cy, ocz = o.z - A.cz;
         const float half_b = (ocx * d.x + ocy * d.y) + ocz * d.z;
-        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - Q.r2[0];
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - A.r2;
         const float disc = half_b * half_b - cc;
         visit(i, disc, half_b);
     }

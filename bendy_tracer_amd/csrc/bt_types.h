@@ -59,9 +59,16 @@ static_assert(sizeof(BtPrim) == 144, "BtPrim must be 144 bytes");
 struct BtSpherePair {
     float cx[2], cy[2], cz[2], radius[2];
     int32_t object[2];
-    float r2[2];            // radius * radius (sphere.rs:130), multiplied once on the host: the same IEEE product
+    int32_t pad[2];
 };
 static_assert(sizeof(BtSpherePair) == 48, "BtSpherePair must be 48 bytes");
+// Sphere-only scenes WITHOUT volumes (scene.json): one 16-byte row per sphere -- a pair of spheres is one s_load_dwordx8, an odd
+// table's last sphere one s_load_dwordx4 (bt_device.hpp intersect_spheres_plain; BtSpherePair costs three loads per pair).
+struct BtSphereRow {
+    float cx, cy, cz;
+    float r2;               // radius * radius (sphere.rs:130), multiplied once on the host: the same IEEE product
+};
+static_assert(sizeof(BtSphereRow) == 16, "BtSphereRow must be 16 bytes");
 
 // Rect scenes without volumes: the BT_PRIM_RECT_AAN rows once more, 32 bytes each, grouped by the axis of the normal
 // (all x-normal rows, then y, then z; ascending row inside a group) -- bt_device.hpp intersect_sorted() walks a group
@@ -221,6 +228,7 @@ struct BtLaunch {
     const int32_t *lens_prims;
     int32_t n_lens_prims;
     float lens_margin;
+    const BtSphereRow *sphere_rows;   // sphere-only scenes without volumes, else null
     // Packed launch (small frames / few samples, bt_api.cpp): n_workgroups workgroups -- one per workgroup slot of the GPU --
     // share the launch's blocks, workgroup w owning blocks w, w + n_workgroups, ... (wg_blocks of them, one less from workgroup
     // wg_blocks_rem on) behind one queue.  wg_blocks = 1: one block per workgroup.
