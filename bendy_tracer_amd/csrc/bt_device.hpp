@@ -404,17 +404,13 @@ BT_DEV HitRec intersect_sphere_pairs(const BtLaunch &P, V3 o, V3 d, float tmin, 
             const float ds = s ? disc.y : disc.x, hb = s ? half_b.y : half_b.x;
             if (!taken && ds >= 0.0f) {                                      // sphere_t()'s root selection
                 const float sqrtd = sqrt_bt(ds);
-                float t = -hb - sqrtd;
-                bool ok = !(t < tmin || t > h.t);
-                if (!ok) {
-                    t = -hb + sqrtd;
-                    ok = !(t < tmin || t > h.t);
-                }
-                if (ok) {
-                    h.t = t;
-                    h.prim = row;
-                    h.inside = false;
-                }
+                // both roots, then selects (as in intersect_spheres_plain: C4 9.50 -> 9.45 ms, cloud 9.61 -> 9.56, profiles/r05l)
+                const float t1 = -hb - sqrtd, t2 = -hb + sqrtd;
+                const bool ok1 = !(t1 < tmin || t1 > h.t), ok2 = !(t2 < tmin || t2 > h.t);
+                const bool ok = ok1 | ok2;
+                h.t = ok ? (ok1 ? t1 : t2) : h.t;
+                h.prim = ok ? row : h.prim;
+                h.inside = ok ? false : h.inside;
             }
         }
     }
