@@ -38,9 +38,6 @@
 // r04e, r04f).
 #include "bt_device.hpp"
 
-#ifndef BT_DRAIN_SHIFT
-#define BT_DRAIN_SHIFT 1           // packed rect build: a drain round every 2^BT_DRAIN_SHIFT iterations
-#endif
 #define BT_SUM_BATCH 8             // parked values a lane of the summing wave has in flight (16: no difference, profiles/r04k)
 
 // Developer build (-DBT_PROFILE): s_memtime stamps around the sections of the render loop, summed per wave into
@@ -388,7 +385,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     };
 
     // Packed builds, the drain (BtLaunch::pool_records > 0): once the queue is empty the workgroup's waves meet at the end of every
-    // second iteration, put the paths still in flight into LDS records and take them back densely packed -- waves 1 .. 3 run out of
+    // iteration, put the paths still in flight into LDS records and take them back densely packed -- waves 1 .. 3 run out of
     // paths and stop issuing instructions for a handful of live lanes each.  Scheduling only: a path's state moves between lanes,
     // its operations and their order do not change.  Every wave takes part in every round (barriers pair up by count) until
     // a round finds no path left.
@@ -808,8 +805,8 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         // the barrier alone, again and again)
         if (compacting && __ballot(dry_lane) != 0ull) {                   // wave-uniform: the queue is empty
             dry_lane = true;
-            if ((drain_it & ((1u << BT_DRAIN_SHIFT) - 1u)) == 0u) {
-                const uint32_t set = (drain_it >> BT_DRAIN_SHIFT) & 1u;
+            {                                                             // a round per iteration (every 2nd: +0.7 %, every 4th: +2 %; profiles/r04z, r05x)
+                const uint32_t set = drain_it & 1u;
                 const bool alive = !pending;                              // a path in flight (possibly holding its hit for the vote)
                 const unsigned long long m = __ballot(alive);
                 uint32_t base = 0;
