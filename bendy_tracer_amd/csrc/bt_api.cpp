@@ -499,7 +499,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     // The drain of a packed launch compacts the paths in flight through LDS records (bt_kernels.hip PathRec, 80 B): room for 128
     // behind the tables, where that does not cost a workgroup slot and the packed record fields are wide enough.
     const size_t pool_offset = (lds_bytes + 15) & ~(size_t)15, pool_bytes = BT_POOL_RECORDS * 80;
-    bool pool_ok = tune.packed != 1 && P.any_rects && !P.any_volumes &&            // (the rect build is the one that has the code)
+    bool pool_ok = tune.packed != 1 && P.any_rects && !P.any_volumes && output == 0 &&   // (the Full-output rect build is the one that has the code)
                    P.max_bounces < 0xfff0 && P.max_volume_bounces < 0xfff0 && s->flat.prims.size() < 0xfffff0u;
     // workgroup slots of the GPU: 7 per CU by the builds' __launch_bounds__ (72 VGPRs), fewer when the scene tables are large
     // (160 KB of LDS per CU, allocated in 2 KB steps here to stay on the safe side)
@@ -512,7 +512,7 @@ int render_common(bt_scene *s, uint64_t camera_ref, const bt_config *cfg, const 
     // their drains with other workgroups' work and lose 5 - 20 % when packed, emptier ones do not fill the slots
     const uint64_t items_all = px_launch * T_launch, lanes_all = (uint64_t)wg_slots * 256;
     const bool pack = tune.packed > 0 || (tune.packed < 0 && items_all > lanes_all && items_all <= 24 * lanes_all);
-    if (pack && chunk == (uint32_t)P.samples && output == 0 && !P.lens_on) {      // (the packed builds: Full output, no lens)
+    if (pack && chunk == (uint32_t)P.samples && !P.lens_on) {                     // (the lens extension has no packed builds)
         // blocks of ~64 / T pixels: one wave's take from the queue is one block's samples (coherent camera rays)
         uint32_t S = 4;
         while (S < 32 && S < 4 * T_launch) S *= 2;

@@ -249,8 +249,8 @@ BT_DEV void sum_blocks(const BtLaunch &P, const BlockGeom &g, uint32_t first, ui
 #endif
 // RECTS = false: sphere-only scenes (scene.json, volume.json, cloud.json) run a build without any rect / cuboid code.
 // VOLS = false: no sphere carries a volume (scene.json, the Cornell boxes): the march and Volume::shade drop out.
-// PACKED = true: the build for packed launches (BtLaunch::wg_blocks > 1; Full output without the lens only), so that the
-// other builds carry none of its code -- as a run-time switch it cost C3 4 % (profiles/r04u).
+// PACKED = true: the builds for packed launches (BtLaunch::wg_blocks > 1; not with the lens extension), so that the
+// other builds carry none of their code -- as a run-time switch it cost C3 4 % (profiles/r04u).
 template <int OUTPUT, bool LENS, bool RECTS, bool VOLS, bool PACKED>
 __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WAVES_PER_SIMD_RECTS : (VOLS ? BT_WAVES_PER_SIMD_VOLS : BT_WAVES_PER_SIMD))) void bt_render_kernel(BtLaunch P) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
         s_waves_done = 0;
         s_next_item = 0;
         s_segments = 0;
-        if (PACKED && RECTS && !VOLS) s_pool_paths[0] = s_pool_paths[1] = s_pool_waves[0] = s_pool_waves[1] = 0;
+        if (PACKED && RECTS && !VOLS && OUTPUT == 0) s_pool_paths[0] = s_pool_paths[1] = s_pool_waves[0] = s_pool_waves[1] = 0;
     }
 
     // ---- stage the per-lane lookup tables in LDS ----
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, LENS ? BT_WAVES_PER_SIMD_LENS : (RECTS ? BT_WA
     PathRec *const pool = (PathRec *)(smem + P.pool_lds_offset);
     // Compiled into the rect build only: measured (profiles/r04y), it takes 4 - 14 % off packed Cornell-box launches and nothing off
     // sphere and volume launches (short drains; marches), whose builds its code made ~5 % slower.
-    constexpr bool CAN_COMPACT = PACKED && RECTS && !VOLS;
+    constexpr bool CAN_COMPACT = PACKED && RECTS && !VOLS && OUTPUT == 0;    // (a PathRec carries no first-hit AOV state)
     const bool compacting = CAN_COMPACT && P.pool_records > 0;
     bool dry_lane = false;             // this lane found the queue empty
     uint32_t drain_it = 0;             // iterations since the wave saw the queue empty (wave-uniform)
@@ -979,8 +979,8 @@ __global__ __launch_bounds__(256) void bt_preview_kernel(const float4 *rgba, uin
 extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream) {
     // grid = tiles to render; a tile is P->slices workgroups (see the mapping in the kernel)
-    const bool packed = P->wg_blocks > 1;          // bt_api.cpp packs Full-output launches without the lens only
-    if (packed && (output != 0 || P->lens_on)) return hipErrorInvalidValue;
+    const bool packed = P->wg_blocks > 1;          // bt_api.cpp packs launches without the lens only
+    if (packed && P->lens_on) return hipErrorInvalidValue;
     dim3 g(packed ? P->n_workgroups : grid * (unsigned)P->slices), b(256);
     // scene classes: bit 0 = some sphere carries a volume (volume.json, cloud.json), bit 1 = rects / cuboids present
     // (the Cornell boxes); scene.json is class 0
@@ -994,25 +994,22 @@ extern "C" hipError_t bt_launch_render(const BtLaunch *P, int output, unsigned g
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
         hipLaunchKernelGGL((bt_render_kernel<O, L, R, V, K>), g, b, lds_bytes, stream, *P);                      \
     } while (0)
-#define BT_LAUNCH_OUT(L, R, V)                                                                                   \
+#define BT_LAUNCH_OUT(L, R, V, K)                                                                                \
     switch (output) {                                                                                            \
-    case 0: BT_LAUNCH(0, L, R, V, false); break;                                                                 \
-    case 1: BT_LAUNCH(1, L, R, V, false); break;                                                                 \
-    case 2: BT_LAUNCH(2, L, R, V, false); break;                                                                 \
-    default: BT_LAUNCH(3, L, R, V, false); break;                                                                \
+    case 0: BT_LAUNCH(0, L, R, V, K); break;                                                                     \
+    case 1: BT_LAUNCH(1, L, R, V, K); break;                                                                     \
+    case 2: BT_LAUNCH(2, L, R, V, K); break;                                                                     \
+    default: BT_LAUNCH(3, L, R, V, K); break;                                                                    \
     }
-#define BT_LAUNCH_CLASS(L)                                                                                       \
-    if (cls == 3) { BT_LAUNCH_OUT(L, true, true) } else if (cls == 2) { BT_LAUNCH_OUT(L, true, false) }            \
-    else if (cls == 1) { BT_LAUNCH_OUT(L, false, true) } else { BT_LAUNCH_OUT(L, false, false) }
+#define BT_LAUNCH_CLASS(L, K)                                                                                    \
+    if (cls == 3) { BT_LAUNCH_OUT(L, true, true, K) } else if (cls == 2) { BT_LAUNCH_OUT(L, true, false, K) }      \
+    else if (cls == 1) { BT_LAUNCH_OUT(L, false, true, K) } else { BT_LAUNCH_OUT(L, false, false, K) }
     if (packed) {
-        if (cls == 3) BT_LAUNCH(0, false, true, true, true);
-        else if (cls == 2) BT_LAUNCH(0, false, true, false, true);
-        else if (cls == 1) BT_LAUNCH(0, false, false, true, true);
-        else BT_LAUNCH(0, false, false, false, true);
+        BT_LAUNCH_CLASS(false, true)
     } else if (P->lens_on) {
-        BT_LAUNCH_CLASS(true)
+        BT_LAUNCH_CLASS(true, false)
     } else {
-        BT_LAUNCH_CLASS(false)
+        BT_LAUNCH_CLASS(false, false)
     }
 #undef BT_LAUNCH_CLASS
 #undef BT_LAUNCH_OUT

@@ -365,7 +365,7 @@ def test_packed_launches(bendy, oracle, name, w, h, samples, n, slices, world, p
 
 def test_packing_is_automatic_for_mid_sized_launches_and_absent_elsewhere(bendy, oracle):
     """bt_api.cpp packs launches of ~1 ... 24 work items per lane of the GPU (the interactive pattern on a 768 x 512 frame:
-    4 rays per pixel, 3.4 items per lane on an MI355X) -- Full output without the lens only: the AOV and lens builds have no packed variant."""
+    4 rays per pixel, 3.4 items per lane on an MI355X), in every Output mode; the lens extension has no packed builds."""
     import torch
     w, h = 768, 512
     it, seg = oracle_render(oracle, "scene", w, h, 1, n=2, threads=16)
@@ -384,10 +384,18 @@ def test_packing_is_automatic_for_mid_sized_launches_and_absent_elsewhere(bendy,
     # a deep launch is never packed on its own
     _, st, _ = gpu_render(bendy, "scene", 320, 200, 300)
     assert st.packed == 0
-    # AOV outputs and the lens extension: asked for, not available -> one block per workgroup, same bits
-    buf, st, _ = gpu_render(bendy, "scene", 400, 260, 2, output=2, tuning={"packed": 1})
-    it2, _ = oracle_render(oracle, "scene", 400, 260, 2, output=2, threads=16)
-    assert st.packed == 0 and np.array_equal(buf.numpy(), it2)
+    # the lens extension has no packed builds: asked for, not available -> one block per workgroup (lens tests compare the pixels)
+    sc, cam = gpu_scene(bendy, "scene", 400, 260, tuning={"packed": 1})
+    sc.set_lens((0.6, 0.4, 4.0), 0.15, 0.1, 6.0, 800)
+    buf = bendy.Buffer.new(400, 260)
+    bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4)).render(sc, cam, bendy.RenderConfig.with_samples(2), buf)
+    torch.cuda.synchronize()
+    assert sc.last_stats().packed == 0
+    # every Output mode has packed builds (the AOV ones without the compacting drain: a path record carries no first-hit state)
+    for name, output in (("scene", 2), ("cornell2", 1), ("volume", 3)):
+        buf, st, _ = gpu_render(bendy, name, 400, 260, 2, output=output, tuning={"packed": 2})
+        it2, seg2 = oracle_render(oracle, name, 400, 260, 2, output=output, threads=16)
+        assert st.packed == 1 and st.segments == seg2 and np.array_equal(buf.numpy(), it2)
 
 
 @pytest.mark.parametrize("max_wait", [0, 1, 2, 7])
