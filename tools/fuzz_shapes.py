@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): launch shapes against the oracle -- random frame sizes (up to 1920x1080), 1 ... 48 samples,
-Subsample 1 ... 3, full frames and rank shards, on the three scene classes; whatever bt_api.cpp picks (slices, launches), and
+Subsample 1 ... 3, every Output mode, full frames and rank shards, on the three scene classes; whatever bt_api.cpp picks (slices, launches), and
 every pinned block shape, must give the oracle's bits.  usage: python3 tools/fuzz_shapes.py [n_cases] [seed]"""
 import json
 import os
@@ -31,13 +31,14 @@ for case in range(n):
     spp = rng.choice([1, 1, 2, 3, 5, 8, 13, 16, 24, 48]) if not big else rng.choice([1, 2, 4])
     sub = rng.choice([0, 0, 2, 3]) if spp <= 8 else 0
     world = rng.choice([1, 1, 1, 2, 3])
+    output = rng.choice([0, 0, 0, 1, 2, 3])                       # Output::{Full, Albedo, Normal, Depth}
     pin = rng.choice([None, None, None, 1, 2, 4, 8, 16, 32])      # bt_tuning.slices: every block shape, not only the automatic one
     packed = rng.choice([-1, 0, 1, 2, 2])                            # bt_tuning.packed: several blocks behind one queue
     tuning = {"packed": packed}
     if pin:
         tuning["slices"] = pin
     sc, cam = gpu_scene(bendy, name, w, h, tuning=tuning)
-    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4))
+    tr = bendy.Tracer.with_config(bendy.Config(chunks_x=8, chunks_y=4, output=bendy.Output(output)))
     rc = bendy.RenderConfig.with_samples_subsample(spp, bendy.Subsample(sub)) if sub else bendy.RenderConfig.with_samples(spp)
     if world == 1:
         buf = bendy.Buffer.new(w, h)
@@ -55,13 +56,13 @@ for case in range(n):
         torch.cuda.synchronize()
         got = out.numpy()
     st = sc.last_stats()
-    it, seg = oracle_render(oracle, name, w, h, spp, n=sub, recursive=0, threads=16)
+    it, seg = oracle_render(oracle, name, w, h, spp, n=sub, output=output, recursive=0, threads=16)
     ok = np.array_equal(got[..., :3], it[..., :3], equal_nan=True)
     key = (st.slices, st.launches, packed, st.packed)
     seen[key] = seen.get(key, 0) + 1
     if not ok:
         bad += 1
-        print(f"MISMATCH case {case}: {name} {w}x{h} spp {spp} sub {sub} world {world} slices {st.slices}", flush=True)
+        print(f"MISMATCH case {case}: {name} {w}x{h} spp {spp} sub {sub} world {world} output {output} slices {st.slices}", flush=True)
     if case % 50 == 49:
         print(f"... {case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print("slices / launches / packed knob / packed launch seen:", dict(sorted(seen.items())))
